@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the IMPORTED reference (read-only, /root/reference).
+
+Runs only in the build container (the reference never travels to the GPU box); the .npz
+files it writes are data: inputs (base codes, targets, the reference's own randomly
+initialised state dict) and the outputs the reference computed for them.
+
+    python tools/make_golden.py            # rewrites every fixture
+
+`Bio` (biopython) is not installed and is not used by the ExplaiNN class; the three stub
+modules below only satisfy the reference's top-of-file imports.
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+for name in ("Bio", "Bio.motifs", "Bio.Seq"):
+    sys.modules.setdefault(name, types.ModuleType(name))
+sys.modules["Bio"].motifs = sys.modules["Bio.motifs"]
+sys.modules["Bio.Seq"].Seq = object
+sys.path.insert(0, "/root/reference/explainn")
+
+import numpy as np
+import torch
+
+from architectures import ExplaiNN, get_loss, get_optimizer   # noqa: E402  (reference)
+import sequence as ref_sequence                                 # noqa: E402  (reference)
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+torch.set_num_threads(1)
+
+
+def make_codes(B, L, seed, n_frac):
+    g = torch.Generator().manual_seed(seed)
+    codes = torch.randint(0, 4, (B, L), generator=g)
+    if n_frac > 0:
+        holes = torch.rand(B, L, generator=g) < n_frac
+        codes[holes] = 4
+    return codes.numpy().astype(np.uint8)
+
+
+def codes_to_onehot(codes):
+    B, L = codes.shape
+    x = np.zeros((B, 4, L), dtype=np.float32)
+    for a in range(4):
+        x[:, a, :] = (codes == a)
+    return x
+
+
+def perturb_bn(model, seed, negative_gamma):
+    """Move BN affine params and running stats off their defaults so eval mode is a real test."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for i in (1, 7, 11):
+            bn = model.linears[i]
+            bn.weight.copy_(1 + 0.3 * torch.randn(bn.weight.shape, generator=g))
+            bn.bias.copy_(0.2 * torch.randn(bn.bias.shape, generator=g))
+            bn.running_mean.copy_(0.1 * torch.randn(bn.bias.shape, generator=g))
+            bn.running_var.copy_(0.5 + torch.rand(bn.bias.shape, generator=g))
+        if negative_gamma:
+            model.linears[1].weight[::2] *= -1      # sign-aware pooling must handle gamma1 < 0
+
+
+def sd_np(model, prefix="sd/"):
+    return {prefix + k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+
+
+def grads_np(model, prefix):
+    return {prefix + k: p.grad.detach().numpy().copy() for k, p in model.named_parameters()}
+
+
+def make_case(name, U, k, L, T, B, seed, n_frac=0.0, negative_gamma=False, loss_kind="binary",
+              n_steps=20, n_batches=3, keep_full=True, tandem=False):
+    torch.manual_seed(seed)
+    model = ExplaiNN(U, k, L, T)
+    perturb_bn(model, seed + 1, negative_gamma)
+    codes = make_codes(B * n_batches, L, seed + 2, n_frac)
+    if tandem:
+        # tandem repeats: equal activations inside pooling windows (tie -> first index)
+        unit = np.array([0, 1, 2, 3, 0, 1, 2], dtype=np.uint8)
+        codes[0] = np.resize(unit, L)
+        codes[1] = 0
+    x_all = torch.from_numpy(codes_to_onehot(codes))
+    g = torch.Generator().manual_seed(seed + 3)
+    if loss_kind == "binary":
+        y_all = (torch.rand(B * n_batches, T, generator=g) > 0.5).float()
+    else:
+        y_all = torch.randn(B * n_batches, T, generator=g)
+    out = dict(cfg=np.array([U, k, L, T, B, n_batches], dtype=np.int64),
+               loss_kind=np.array(loss_kind), codes=codes, y=y_all.numpy())
+    out.update(sd_np(model, "sd/"))
+    x, y = x_all[:B], y_all[:B]
+    crit = get_loss("binary" if loss_kind == "binary" else "linear")
+
+    # ---- eval mode: logits, unit outputs, per-position activations (test.py:148-160) ----
+    model.eval()
+    with torch.no_grad():
+        out["eval/logits"] = model(x).numpy()
+        xr = x.repeat(1, U, 1)
+        out["eval/outs"] = model.linears(xr).numpy()
+        if keep_full:
+            out["eval/acts"] = model.linears[:3](xr).numpy()
+        # predict.py:75-94
+        rev = torch.from_numpy(np.ascontiguousarray(
+            ref_sequence.rc_one_hot_encoding_many(x.numpy())))
+        f_ = model(x).numpy()[:, :, None]; r_ = model(rev).numpy()[:, :, None]
+        fr = np.concatenate((f_, r_), axis=2)
+        out["eval/predict"] = np.concatenate(
+            (f_, r_, fr.mean(axis=2, keepdims=True), fr.max(axis=2, keepdims=True)), axis=2
+        ).astype(np.float64)
+
+    # ---- train mode, dropout p=0: one fwd+bwd (selene/__init__.py:283-291) ----
+    state0 = {k_: v.clone() for k_, v in model.state_dict().items()}
+    model.train()
+    model.linears[9].p = 0.0
+    model.zero_grad()
+    logits = model(x)
+    loss = crit(logits, y)
+    loss.backward()
+    out["train0/logits"] = logits.detach().numpy()
+    out["train0/loss"] = np.array(loss.item())
+    gr = grads_np(model, "train0/grad/")
+    if not keep_full:
+        big = gr.pop("train0/grad/linears.6.weight")
+        rng = np.random.default_rng(7)
+        out["train0/grad_proj/linears.6.weight"] = np.array(
+            [(big[:, :, 0] * rng.standard_normal(big.shape[:2])).sum(), np.abs(big).sum()])
+        out["train0/grad_rows/linears.6.weight"] = big[:200].copy()
+    out.update(gr)
+    out.update({"train0/buf/" + k_: v.numpy().copy() for k_, v in model.state_dict().items()
+                if "running" in k_ or "tracked" in k_})
+
+    # ---- train mode with the reference's own dropout; keep-mask captured by a hook ----
+    model.load_state_dict(state0)
+    model.linears[9].p = 0.3
+    captured = {}
+    hook = model.linears[9].register_forward_hook(
+        lambda mod, inp, outp: captured.__setitem__("keep", (outp != 0).squeeze(-1)))
+    torch.manual_seed(seed + 4)
+    model.zero_grad()
+    logits = model(x)
+    loss = crit(logits, y)
+    loss.backward()
+    hook.remove()
+    # where the ReLU output is 0 the mask is irrelevant; (out != 0) is a valid keep-mask
+    out["drop/keep_bits"] = np.packbits(captured["keep"].numpy().astype(np.uint8), axis=1)
+    out["drop/logits"] = logits.detach().numpy()
+    out["drop/loss"] = np.array(loss.item())
+    for key in ("linears.0.weight", "linears.1.weight", "linears.1.bias", "linears.7.weight",
+                "linears.10.weight", "linears.11.weight", "final.weight", "final.bias"):
+        out["drop/grad/" + key] = dict(model.named_parameters())[key].grad.numpy().copy()
+
+    # ---- n_steps Adam steps (lr 0.003), p=0, batches cycled ----
+    model.load_state_dict(state0)
+    model.linears[9].p = 0.0
+    opt = get_optimizer(model.parameters(), 0.003)
+    losses, lg = [], []
+    for step in range(1, n_steps + 1):
+        i = (step - 1) % n_batches
+        xb, yb = x_all[i * B:(i + 1) * B], y_all[i * B:(i + 1) * B]
+        model.train()
+        pred = model(xb)
+        ls = crit(pred, yb)
+        opt.zero_grad(); ls.backward(); opt.step()
+        losses.append(ls.item()); lg.append(pred.detach().numpy().copy())
+        if step in (1, 5, 20):
+            snap = sd_np(model, "step%d/sd/" % step)
+            if not keep_full:
+                snap = {k_: v for k_, v in snap.items() if "linears.6" not in k_
+                        and "linears.7" not in k_}
+            out.update(snap)
+            if step == 1:
+                st = opt.state_dict()["state"]
+                names = [k_ for k_, _ in model.named_parameters()]
+                for j, nm in enumerate(names):
+                    if keep_full or "linears.6" not in nm and "linears.7" not in nm:
+                        out["step1/adam/exp_avg/" + nm] = st[j]["exp_avg"].numpy().copy()
+                        out["step1/adam/exp_avg_sq/" + nm] = st[j]["exp_avg_sq"].numpy().copy()
+    out["steps/loss"] = np.array(losses)
+    out["steps/logits"] = np.stack(lg)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("%-28s %8.1f KB" % (name, os.path.getsize(path) / 1024))
+
+
+def make_encoding_case():
+    seqs = ["ACGT", "acgtn", "NNACGTRYACGT", "TTTTGGGGCCCCAAAA", "A"]
+    out = {}
+    for i, s in enumerate(seqs):
+        enc = ref_sequence.one_hot_encode(s)
+        out["seq%d" % i] = np.array(s)
+        out["enc%d" % i] = enc
+        out["rc%d" % i] = np.ascontiguousarray(ref_sequence.rc_one_hot_encoding(enc))
+    np.savez_compressed(os.path.join(OUT, "encoding.npz"), **out)
+    print("encoding")
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    make_encoding_case()
+    #          name               U   k   L   T   B  seed
+    make_case("tiny_u1_k5",       1,  5,  26, 1,  2, 10)
+    make_case("tiny_u3_k5_N",     3,  5,  26, 3, 16, 11, n_frac=0.1, negative_gamma=True)
+    make_case("small_u8_k19",     8, 19,  60, 3, 16, 12, negative_gamma=True)
+    make_case("small_u8_k19_mse", 8, 19,  61, 2, 16, 13, n_frac=0.02, loss_kind="linear")
+    make_case("tandem_u3_k5",     3,  5,  40, 1,  8, 14, tandem=True)
+    make_case("mid_u8_k19_L200",  8, 19, 200, 1, 16, 15, n_frac=0.01, negative_gamma=True)
+    make_case("c1_u100_k19_L200", 100, 19, 200, 1, 64, 16, n_steps=5, n_batches=2,
+              keep_full=False)
