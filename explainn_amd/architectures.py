@@ -1,0 +1,433 @@
+"""Drop-in `ExplaiNN` nn.Module whose forward/backward run as hand-written gfx950 kernels.
+
+Mirrors the reference's module surface for this path (reference: explainn/architectures/__init__.py):
+  * constructor `ExplaiNN(cnn_units, kernel_size, sequence_length, n_features=1, weights_file=None)`
+    and `_options`                                                         (:44-67)
+  * `state_dict()` keys/shapes `linears.{0,1,6,7,10,11}.*`, `final.*`      (:72-104)
+  * `forward(x)`: x (B,4,L) fp32 one-hot -> logits (B,T); train mode uses batch statistics,
+    updates the BatchNorm buffers and applies Dropout(0.3)                 (:109-114)
+  * `model.linears[0].weight`, `model.linears(x_rep)`, `model.linears[:3](x_rep)`,
+    `model.final(outs)` as test.py:148-160 / train.py:318-324 / selene/__init__.py:257 use them
+  * `get_loss`, `get_metrics`, `get_optimizer`                             (:446-464)
+
+The compute is in libexplainn_hip.so (include/explainn_hip.h); PyTorch only owns the device
+memory, the stream and autograd bookkeeping.  There is no CPU or eager fallback: a model that is
+not on a HIP device raises.
+"""
+import copy
+import ctypes as C
+import math
+import weakref
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+FC_HIDDEN = 100
+POOL = 7
+DROPOUT_P = 0.3
+
+
+# ----------------------------------------------------------------------------------------------
+# parameter holders (positions 0,1,6,7,10,11 of `linears`; the other positions hold no state)
+# ----------------------------------------------------------------------------------------------
+def _uniform_fan_in_(weight, bias, fan_in):
+    """torch's default Conv1d/Linear init: U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for both."""
+    bound = 1.0 / math.sqrt(fan_in) if fan_in > 0 else 0.0
+    with torch.no_grad():
+        weight.uniform_(-bound, bound)
+        bias.uniform_(-bound, bound)
+
+
+class _GroupedTaps(nn.Module):
+    """weight/bias of a grouped Conv1d; holds state only (the kernels do the math)."""
+
+    def __init__(self, out_channels, in_per_group, kernel_size):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(out_channels, in_per_group, kernel_size))
+        self.bias = nn.Parameter(torch.empty(out_channels))
+        _uniform_fan_in_(self.weight, self.bias, in_per_group * kernel_size)
+
+    def forward(self, *a, **k):
+        raise RuntimeError("sub-layers are fused; call model(x), model.linears(x_rep) or "
+                           "model.linears[:3](x_rep)")
+
+
+class _BatchStats(nn.Module):
+    """BatchNorm1d state: affine parameters and running statistics."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(channels))
+        self.bias = nn.Parameter(torch.zeros(channels))
+        self.register_buffer("running_mean", torch.zeros(channels))
+        self.register_buffer("running_var", torch.ones(channels))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    forward = _GroupedTaps.forward
+
+
+class _Fused(nn.Module):
+    """Stateless stage (exp, max-pool, flatten, ReLU, dropout) -- fused into the kernels."""
+
+    def __init__(self, what):
+        super().__init__()
+        self.what = what
+
+    def extra_repr(self):
+        return self.what
+
+    forward = _GroupedTaps.forward
+
+
+class _UnitPrefix:
+    """`model.linears[:3]` -- conv + BatchNorm + exp per position (test.py:159-160)."""
+
+    def __init__(self, owner):
+        self._owner = owner
+
+    def __call__(self, x_rep):
+        return self._owner._unit_activations(x_rep)
+
+
+class _UnitStack(nn.Sequential):
+    """The `linears` container: real parameters at the reference's indices, fused forward."""
+
+    def _bind(self, owner):
+        self.__dict__["_owner_ref"] = weakref.ref(owner)
+
+    def _owner(self):
+        owner = self.__dict__["_owner_ref"]()
+        if owner is None:
+            raise RuntimeError("owning ExplaiNN module is gone")
+        return owner
+
+    def forward(self, x_rep):
+        return self._owner()._unit_outputs(x_rep)
+
+    def __getitem__(self, idx):
+        if isinstance(idx, slice):
+            if idx == slice(None, 3, None) or idx == slice(0, 3, None):
+                return _UnitPrefix(self._owner())
+            raise NotImplementedError("only linears[:3] (conv+BN+exp) is exposed as a sub-stack")
+        return super().__getitem__(idx)
+
+
+class _Runtime:
+    """Per-model device context; never copied or pickled with the module."""
+
+    def __init__(self):
+        self.ctx = None
+        self.token = 0
+        self.pending = None
+
+    def __deepcopy__(self, memo):
+        return _Runtime()
+
+    def __getstate__(self):
+        return {}
+
+    def __setstate__(self, state):
+        self.__init__()
+
+
+class _TrainStep(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        ctx.model = model
+        logits, ctx.token = model._launch_train(x)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        grads = ctx.model._launch_backward(dlogits, ctx.token)
+        return (None, None) + tuple(grads)
+
+
+class _Model(nn.Module):
+
+    def load_weights(self, weight_file):
+        """architectures/__init__.py:27-39: positional remap of a saved tensor list onto this
+        module's keys.  Accepts both the (100U,n,1)/(U,100,1) layout of this class's own
+        state_dict and the squeezed (100U,n)/(U,100) layout of the older Linear-based variant."""
+        sd = torch.load(weight_file, map_location="cpu", weights_only=True)
+        own = self.state_dict()
+        keys = list(own.keys())
+        remapped = OrderedDict()
+        for key, v in zip(keys, sd.values()):
+            if v.dim() == own[key].dim() - 1:
+                v = v.unsqueeze(-1)
+            elif v.dim() == own[key].dim() + 1 and v.shape[-1] == 1:
+                v = v.squeeze(-1)
+            remapped[key] = v
+        self.load_state_dict(remapped)
+
+
+class ExplaiNN(_Model):
+    """ExplaiNN: explainable neural networks (MI355X-native forward/backward)."""
+
+    def __init__(self, cnn_units, kernel_size, sequence_length, n_features=1, weights_file=None):
+        super().__init__()
+        self._options = {
+            "cnn_units": cnn_units,
+            "kernel_size": kernel_size,
+            "sequence_length": sequence_length,
+            "n_features": n_features,
+            "weights_file": weights_file,
+        }
+        n = int(math.floor((sequence_length - kernel_size + 1) / float(POOL)))
+        if n < 1:
+            raise ValueError("sequence_length too short for kernel_size and MaxPool1d(7, 7)")
+        self._n = n
+        U = cnn_units
+        self.linears = _UnitStack(
+            _GroupedTaps(U, 4, kernel_size),                 # 0  Conv1d(4U->U, k, groups=U)
+            _BatchStats(U),                                  # 1  BatchNorm1d(U)
+            _Fused("exp"),                                   # 2
+            _Fused("max_pool1d(7, 7)"),                      # 3
+            _Fused("flatten"),                               # 4
+            _Fused("unsqueeze(-1)"),                         # 5
+            _GroupedTaps(FC_HIDDEN * U, n, 1),               # 6  per-unit Linear(n->100)
+            _BatchStats(FC_HIDDEN * U),                      # 7  BatchNorm1d(100U)
+            _Fused("relu"),                                  # 8
+            _Fused("dropout(p=%g)" % DROPOUT_P),             # 9
+            _GroupedTaps(U, FC_HIDDEN, 1),                   # 10 per-unit Linear(100->1)
+            _BatchStats(U),                                  # 11 BatchNorm1d(U)
+            _Fused("relu"),                                  # 12
+            _Fused("flatten"),                               # 13
+        )
+        self.linears._bind(self)
+        self.final = nn.Linear(U, n_features)
+        self.dropout_p = DROPOUT_P
+        self.validate_input = True
+        self.grad_sync = None          # optional callable(flat_grad_tensor): multi-GPU all-reduce
+        self._rt = _Runtime()
+        if weights_file is not None:
+            self.load_weights(weights_file)
+
+    # -- module protocol ------------------------------------------------------------------
+    def __deepcopy__(self, memo):
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for key, val in self.__dict__.items():
+            new.__dict__[key] = _Runtime() if key == "_rt" else copy.deepcopy(val, memo)
+        new.linears._bind(new)
+        return new
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self.__dict__["_rt"] = _Runtime()
+        self.linears._bind(self)
+
+    # -- plumbing -------------------------------------------------------------------------
+    def _device(self):
+        dev = self.final.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError(
+                "explainn_amd.ExplaiNN runs only on a HIP device (model is on %s): call "
+                ".cuda()/.to('cuda'). There is no CPU fallback." % dev)
+        return dev
+
+    def _context(self, B, dev):
+        o = self._options
+        geom = (o["cnn_units"], o["kernel_size"], o["sequence_length"], o["n_features"])
+        ctx = self._rt.ctx
+        index = dev.index if dev.index is not None else torch.cuda.current_device()
+        if ctx is None or ctx.geom != geom or ctx.device != index or ctx.max_batch < B:
+            if ctx is not None:
+                torch.cuda.synchronize(dev)
+                ctx.close()
+            cap = max(B, ctx.max_batch if ctx is not None and ctx.geom == geom else 0)
+            self._rt.ctx = _lib.Context(*geom, max_batch=cap, device=index)
+        return self._rt.ctx
+
+    def _tensors(self):
+        sd = {k: v for k, v in self.named_parameters()}
+        sd.update({k: v for k, v in self.named_buffers()})
+        return sd
+
+    def _params_struct(self, dev):
+        sd = self._tensors()
+        ps = _lib.Params()
+        keep = []
+        for field in _lib.PARAM_FIELDS:
+            t = sd[_lib.PARAM_KEYS[field]]
+            want = torch.int64 if field.endswith("nbt") else torch.float32
+            if t.device != dev or t.dtype != want:
+                raise RuntimeError("parameter %s must be %s on %s (is %s on %s)" % (
+                    _lib.PARAM_KEYS[field], want, dev, t.dtype, t.device))
+            if not t.is_contiguous():
+                raise RuntimeError("parameter %s must be contiguous" % _lib.PARAM_KEYS[field])
+            keep.append(t)
+            setattr(ps, field, t.data_ptr())
+        return ps, keep
+
+    def _prep_input(self, x, dev):
+        o = self._options
+        if x.dim() != 3 or x.shape[1] != 4 or x.shape[2] != o["sequence_length"]:
+            raise RuntimeError("expected input of shape (B, 4, %d), got %s" % (
+                o["sequence_length"], tuple(x.shape)))
+        if x.device != dev:
+            raise RuntimeError("input is on %s but the model is on %s" % (x.device, dev))
+        return x.detach().to(torch.float32).contiguous()
+
+    def _stream(self, dev):
+        return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def _check_flags(self, ctx, dev):
+        if not self.validate_input:
+            return
+        flags = C.c_int(0)
+        _lib.check(ctx.lib.explainn_input_flags(ctx.handle, C.byref(flags), self._stream(dev)))
+        if flags.value & 1:
+            raise ValueError(
+                "input is not one-hot: every column of x must be one-hot (A,C,G,T) or all-zero "
+                "(N) as sequence.one_hot_encode produces; soft inputs are not supported")
+
+    def input_flags(self):
+        """Synchronise and return (then clear) the device-side input validation flags."""
+        ctx = self._rt.ctx
+        if ctx is None:
+            return 0
+        dev = self._device()
+        flags = C.c_int(0)
+        _lib.check(ctx.lib.explainn_input_flags(ctx.handle, C.byref(flags), self._stream(dev)))
+        return flags.value
+
+    # -- forward / backward ---------------------------------------------------------------
+    def forward(self, x):
+        """Forward propagation of a batch: (B,4,L) one-hot -> (B,T) logits."""
+        dev = self._device()
+        if self.training:
+            if torch.is_grad_enabled():
+                return _TrainStep.apply(self, x, *self.parameters())
+            return self._launch_train(x)[0]
+        x = self._prep_input(x, dev)
+        B = x.shape[0]
+        ctx = self._context(B, dev)
+        ps, keep = self._params_struct(dev)
+        logits = torch.empty(B, self._options["n_features"], device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(ctx.lib.explainn_forward_eval(ctx.handle, x.data_ptr(), B, C.byref(ps),
+                                                     logits.data_ptr(), self._stream(dev)))
+            self._check_flags(ctx, dev)
+        return logits
+
+    def _launch_train(self, x, keep_mask=None):
+        dev = self._device()
+        x = self._prep_input(x, dev)
+        B = x.shape[0]
+        ctx = self._context(B, dev)
+        ps, keep = self._params_struct(dev)
+        logits = torch.empty(B, self._options["n_features"], device=dev, dtype=torch.float32)
+        mask = self._rt.pending if keep_mask is None else keep_mask
+        self._rt.pending = None
+        mask_ptr = None
+        if mask is not None:
+            mask = mask.to(device=dev, dtype=torch.uint8).contiguous()
+            if mask.numel() != B * FC_HIDDEN * self._options["cnn_units"]:
+                raise RuntimeError("keep-mask must have shape (B, 100*cnn_units)")
+            mask_ptr = mask.data_ptr()
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if self.dropout_p > 0 else 0
+        with torch.cuda.device(dev):
+            _lib.check(ctx.lib.explainn_forward_train(
+                ctx.handle, x.data_ptr(), B, C.byref(ps), mask_ptr, float(self.dropout_p),
+                C.c_uint64(seed), logits.data_ptr(), self._stream(dev)))
+            self._check_flags(ctx, dev)
+        self._rt.token += 1
+        return logits, self._rt.token
+
+    def set_dropout_mask(self, keep_mask):
+        """Use `keep_mask` ((B,100U), nonzero = keep) instead of the generator for the NEXT
+        train-mode forward (parity testing against a recorded reference mask)."""
+        self._rt.pending = keep_mask
+
+    def _launch_backward(self, dlogits, token):
+        if token != self._rt.token:
+            raise RuntimeError("backward of a stale forward: the fused kernels keep one training "
+                               "step in flight per model (call backward before the next forward)")
+        dev = self._device()
+        ctx = self._rt.ctx
+        ps, keep = self._params_struct(dev)
+        params = list(self.parameters())
+        flat = torch.empty(sum(p.numel() for p in params), device=dev, dtype=torch.float32)
+        views, off = [], 0
+        gs = _lib.Grads()
+        for field, p in zip(_lib.GRAD_FIELDS, params):
+            v = flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+            views.append(v)
+            setattr(gs, field, v.data_ptr())
+        dl = dlogits.to(torch.float32).contiguous()
+        B = dl.shape[0]
+        with torch.cuda.device(dev):
+            _lib.check(ctx.lib.explainn_backward(ctx.handle, dl.data_ptr(), B, C.byref(ps),
+                                                 C.byref(gs), 0, self._stream(dev)))
+        if self.grad_sync is not None:
+            self.grad_sync(flat)
+        return views
+
+    # -- the façade test.py / interpret.py use -----------------------------------------------
+    def _first_four_rows(self, x_rep):
+        U = self._options["cnn_units"]
+        if x_rep.dim() != 3 or x_rep.shape[1] not in (4, 4 * U):
+            raise RuntimeError("expected the repeated input (B, 4*cnn_units, L) or (B, 4, L)")
+        return x_rep[:, :4, :]
+
+    def _unit_outputs(self, x_rep):
+        """`model.linears(x.repeat(1,U,1))` -> per-unit outputs (B,U) (test.py:151)."""
+        if self.training:
+            raise NotImplementedError("linears(x) is an eval-mode export path; call model.eval()")
+        dev = self._device()
+        x = self._prep_input(self._first_four_rows(x_rep), dev)
+        B = x.shape[0]
+        ctx = self._context(B, dev)
+        ps, keep = self._params_struct(dev)
+        outs = torch.empty(B, self._options["cnn_units"], device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(ctx.lib.explainn_unit_outputs(ctx.handle, x.data_ptr(), B, C.byref(ps),
+                                                     outs.data_ptr(), self._stream(dev)))
+            self._check_flags(ctx, dev)
+        return outs
+
+    def _unit_activations(self, x_rep):
+        """`model.linears[:3](x.repeat(1,U,1))` -> exp(BN(conv)) (B,U,L-k+1) (test.py:159-160)."""
+        if self.training:
+            raise NotImplementedError("linears[:3](x) is an eval-mode export path; call model.eval()")
+        dev = self._device()
+        x = self._prep_input(self._first_four_rows(x_rep), dev)
+        B = x.shape[0]
+        o = self._options
+        ctx = self._context(B, dev)
+        ps, keep = self._params_struct(dev)
+        acts = torch.empty(B, o["cnn_units"], o["sequence_length"] - o["kernel_size"] + 1,
+                           device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(ctx.lib.explainn_unit_activations(ctx.handle, x.data_ptr(), B, C.byref(ps),
+                                                         acts.data_ptr(), self._stream(dev)))
+            self._check_flags(ctx, dev)
+        return acts
+
+
+# ----------------------------------------------------------------------------------------------
+def get_loss(input_data="binary"):
+    """architectures/__init__.py:446-456."""
+    if input_data == "binary":
+        return nn.BCEWithLogitsLoss()
+    return nn.MSELoss()
+
+
+def get_metrics(input_data="binary"):
+    """architectures/__init__.py:458-461."""
+    if input_data == "binary":
+        from sklearn.metrics import average_precision_score, roc_auc_score
+        return dict(aucROC=roc_auc_score, aucPR=average_precision_score)
+    from scipy.stats import pearsonr, spearmanr
+    return dict(Pearson=pearsonr, Spearman=spearmanr)
+
+
+def get_optimizer(params, lr=1e-03):
+    """architectures/__init__.py:463-464."""
+    return torch.optim.Adam(params, lr=lr)

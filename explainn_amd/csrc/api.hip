@@ -1,0 +1,290 @@
+// extern "C" entry points of libexplainn_hip.so (declared in include/explainn_hip.h) and the
+// context that owns the device scratch.  Each entry point enqueues its pipeline stages on the
+// caller's stream and returns; see DESIGN.md section 3 for the stage list.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void explainn_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* explainn_last_error(void) { return g_err; }
+
+namespace {
+struct Carver {
+    int64_t off = 0;
+    char* base = nullptr;
+    template <typename T>
+    void take(T** p, int64_t count) {
+        off = (off + 255) & ~int64_t(255);
+        if (base) *p = reinterpret_cast<T*>(base + off);
+        off += count * (int64_t)sizeof(T);
+    }
+};
+
+void carve(explainn_ctx* c, Carver& cv) {
+    const int64_t U = c->U, U4 = c->U4, n = c->n, Bs = c->Bs, NS = c->NS, K4 = c->K4;
+    cv.take(&c->codesT, (int64_t)c->L * Bs);
+    cv.take(&c->pk2, (int64_t)c->PW * Bs);
+    cv.take(&c->nmask, (int64_t)c->NW * Bs);
+    cv.take(&c->cnt, (int64_t)c->k * c->L * 16);
+    cv.take(&c->G, K4 * K4);
+    cv.take(&c->m, K4);
+    cv.take(&c->alpha, U4);
+    cv.take(&c->shift, U4);
+    cv.take(&c->mug, U4);
+    cv.take(&c->sig1, U4);
+    cv.take(&c->Gw, U4 * K4);
+    cv.take(&c->Wt, (int64_t)c->Uq * c->k * 20);
+    cv.take(&c->ext, U4 * n * Bs);
+    cv.take(&c->idx, U4 * n * Bs);
+    cv.take(&c->qbw, U * Bs * NS);
+    cv.take(&c->qs0, U * NS);
+    cv.take(&c->qS1p, U * c->QCH * NS);
+    cv.take(&c->qS2p, U * c->QCH * NS * NS);
+    cv.take(&c->qbar, U * NS);
+    cv.take(&c->C, U * NS * NS);
+    cv.take(&c->A2, U * FC_H * NS);
+    cv.take(&c->sh2, U * FC_H);
+    cv.take(&c->sig2, U * FC_H);
+    cv.take(&c->z, U * Bs);
+    cv.take(&c->zhat, U * Bs);
+    cv.take(&c->o, U * Bs);
+    cv.take(&c->sig3, U);
+    cv.take(&c->bits, U * Bs);
+    cv.take(&c->dz, U * Bs);
+    cv.take(&c->EQp, U * c->ACH * FC_H * NS);
+    cv.take(&c->Sep, U * c->ACH * FC_H);
+    cv.take(&c->EQs, U * FC_H * NS);
+    cv.take(&c->md2, U * FC_H);
+    cv.take(&c->md2h, U * FC_H);
+    cv.take(&c->Tt, U * FC_H * NS);
+    cv.take(&c->M, U * NS * NS);
+    cv.take(&c->k0p, U * NS);
+    cv.take(&c->dy, U4 * n * Bs);
+    cv.take(&c->S12p, U * (Bs / 64) * 2);
+    cv.take(&c->Dspp, U * (Bs / 64) * K4);
+    cv.take(&c->dlogits, (int64_t)c->maxB * c->T);
+    cv.take(&c->flags, 64);
+    cv.off = (cv.off + 255) & ~int64_t(255);
+}
+
+int check_batch(const explainn_ctx* c, int B) {
+    if (!c) { explainn_set_error("null context"); return EXPLAINN_E_ARG; }
+    if (B < 1 || B > c->maxB) {
+        explainn_set_error("batch %d outside [1, max_batch=%d]", B, c->maxB);
+        return EXPLAINN_E_ARG;
+    }
+    return EXPLAINN_OK;
+}
+
+#define TRY(call)                    \
+    do {                             \
+        int rc_ = (call);            \
+        if (rc_ != EXPLAINN_OK) return rc_; \
+    } while (0)
+
+int eval_front(explainn_ctx* c, const float* x, int B, const explainn_params* p, hipStream_t s) {
+    TRY(launch_pack(c, x, B, false, s));
+    TRY(launch_prep1(c, p, B, false, s));
+    return EXPLAINN_OK;
+}
+}  // namespace
+
+extern "C" int explainn_create(explainn_ctx** out, int cnn_units, int kernel_size,
+                               int sequence_length, int n_features, int max_batch, int device) {
+    if (!out) { explainn_set_error("out is null"); return EXPLAINN_E_ARG; }
+    *out = nullptr;
+    if (cnn_units < 1 || n_features < 1 || max_batch < 1) {
+        explainn_set_error("cnn_units, n_features and max_batch must be positive");
+        return EXPLAINN_E_ARG;
+    }
+    if (kernel_size < 2 || kernel_size > MAX_K) {
+        explainn_set_error("kernel_size %d unsupported (2..%d)", kernel_size, MAX_K);
+        return EXPLAINN_E_UNSUPPORTED;
+    }
+    const int Lo = sequence_length - kernel_size + 1;
+    const int n = Lo / POOLW;
+    if (n < 1) {
+        explainn_set_error("sequence_length %d too short for kernel_size %d and MaxPool1d(7,7)",
+                           sequence_length, kernel_size);
+        return EXPLAINN_E_ARG;
+    }
+    const int NQ = nq_bucket(n);
+    if (NQ == 0) {
+        explainn_set_error("pooled length n=%d exceeds the largest instantiated kernel (%d)", n, MAX_NQ);
+        return EXPLAINN_E_UNSUPPORTED;
+    }
+    HIP_TRY(hipSetDevice(device));
+    explainn_ctx* c = new explainn_ctx();
+    memset(c, 0, sizeof(*c));
+    c->U = cnn_units; c->k = kernel_size; c->L = sequence_length; c->T = n_features;
+    c->maxB = max_batch; c->device = device;
+    c->Lo = Lo; c->n = n; c->U4 = (cnn_units + 3) & ~3; c->Uq = c->U4 / 4;
+    c->NQ = NQ; c->NS = (NQ + 3) & ~3; c->Bs = (max_batch + 63) & ~63; c->K4 = 4 * kernel_size;
+    c->NW = (sequence_length + 31) / 32 + 2; c->PW = 2 * c->NW;
+    {
+        int q = (max_batch + 127) / 128;
+        const int64_t per = (int64_t)c->U * c->NS * c->NS * 4;
+        const int cap = (int)((int64_t)(64 << 20) / (per > 0 ? per : 1));
+        if (q > 8) q = 8;
+        if (q > cap) q = cap;
+        if (q < 1) q = 1;
+        c->QCH = q;
+        int a = (max_batch + 127) / 128;
+        if (a > 16) a = 16;
+        if (a < 1) a = 1;
+        c->ACH = a;
+    }
+    Carver dry;
+    carve(c, dry);
+    c->bytes = dry.off;
+    hipError_t e = hipMalloc(&c->base, c->bytes);
+    if (e != hipSuccess) {
+        explainn_set_error("hipMalloc(%lld bytes) failed: %s", (long long)c->bytes, hipGetErrorString(e));
+        delete c;
+        return EXPLAINN_E_HIP;
+    }
+    Carver real;
+    real.base = c->base;
+    carve(c, real);
+    e = hipMemset(c->base, 0, c->bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        explainn_set_error("scratch memset failed: %s", hipGetErrorString(e));
+        hipFree(c->base);
+        delete c;
+        return EXPLAINN_E_HIP;
+    }
+    int rc = prep_configure(c);
+    if (rc == EXPLAINN_OK) rc = bwd_configure(c);
+    if (rc != EXPLAINN_OK) { hipFree(c->base); delete c; return rc; }
+    *out = c;
+    return EXPLAINN_OK;
+}
+
+extern "C" void explainn_destroy(explainn_ctx* c) {
+    if (!c) return;
+    if (c->base) hipFree(c->base);
+    delete c;
+}
+
+extern "C" int64_t explainn_scratch_bytes(const explainn_ctx* c) { return c ? c->bytes : 0; }
+
+extern "C" int explainn_forward_eval(explainn_ctx* c, const float* x, int B,
+                                     const explainn_params* p, float* logits, void* stream) {
+    TRY(check_batch(c, B));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    TRY(eval_front(c, x, B, p, s));
+    TRY(launch_conv_pool(c, B, s));
+    TRY(launch_prep2(c, p, B, false, s));
+    TRY(launch_fc_fwd(c, p, B, false, nullptr, 0.f, 0, s));
+    TRY(launch_head_fwd(c, p, B, false, logits, nullptr, s));
+    return EXPLAINN_OK;
+}
+
+extern "C" int explainn_unit_outputs(explainn_ctx* c, const float* x, int B,
+                                     const explainn_params* p, float* outs, void* stream) {
+    TRY(check_batch(c, B));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    TRY(eval_front(c, x, B, p, s));
+    TRY(launch_conv_pool(c, B, s));
+    TRY(launch_prep2(c, p, B, false, s));
+    TRY(launch_fc_fwd(c, p, B, false, nullptr, 0.f, 0, s));
+    TRY(launch_head_fwd(c, p, B, false, nullptr, outs, s));
+    return EXPLAINN_OK;
+}
+
+extern "C" int explainn_unit_activations(explainn_ctx* c, const float* x, int B,
+                                         const explainn_params* p, float* acts, void* stream) {
+    TRY(check_batch(c, B));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    TRY(eval_front(c, x, B, p, s));
+    TRY(launch_conv_act(c, B, acts, s));
+    return EXPLAINN_OK;
+}
+
+extern "C" int explainn_forward_train(explainn_ctx* c, const float* x, int B,
+                                      const explainn_params* p, const uint8_t* keep_mask,
+                                      float dropout_p, uint64_t seed, float* logits, void* stream) {
+    TRY(check_batch(c, B));
+    if (B == 1) {
+        // torch raises here (BatchNorm over one value); the reason for train.py:297-302
+        explainn_set_error("Expected more than 1 value per channel when training, got input size "
+                           "[1, %d, 1]", FC_H * c->U);
+        return EXPLAINN_E_BATCH1;
+    }
+    if (dropout_p < 0.f || dropout_p >= 1.f) {
+        explainn_set_error("dropout_p must be in [0,1)");
+        return EXPLAINN_E_ARG;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    c->fwd_B = 0;
+    TRY(launch_pack(c, x, B, true, s));
+    TRY(launch_prep1(c, p, B, true, s));
+    TRY(launch_conv_pool(c, B, s));
+    TRY(launch_qmoments(c, B, s));
+    TRY(launch_prep2(c, p, B, true, s));
+    TRY(launch_fc_fwd(c, p, B, true, keep_mask, dropout_p, seed, s));
+    TRY(launch_head_fwd(c, p, B, true, logits, nullptr, s));
+    c->fwd_B = B;
+    return EXPLAINN_OK;
+}
+
+extern "C" int explainn_backward(explainn_ctx* c, const float* dlogits, int B,
+                                 const explainn_params* p, const explainn_grads* g,
+                                 int freeze_top_n_filters, void* stream) {
+    TRY(check_batch(c, B));
+    if (c->fwd_B != B) {
+        explainn_set_error("backward(B=%d) without a matching train-mode forward (last B=%d)", B,
+                           c->fwd_B);
+        return EXPLAINN_E_STATE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    TRY(launch_head_bwd(c, p, g, dlogits, B, s));
+    TRY(launch_passA(c, B, s));
+    TRY(launch_mid_bwd(c, p, g, B, s));
+    TRY(launch_passB(c, B, s));
+    TRY(launch_conv_bwd(c, B, s));
+    TRY(launch_fin_bwd(c, p, g, B, freeze_top_n_filters, s));
+    return EXPLAINN_OK;
+}
+
+extern "C" int explainn_loss_grad(explainn_ctx* c, int loss_kind, const float* logits,
+                                  const float* targets, int B, float* loss_out, float* dlogits,
+                                  void* stream) {
+    TRY(check_batch(c, B));
+    if (loss_kind != EXPLAINN_LOSS_BCE_WITH_LOGITS && loss_kind != EXPLAINN_LOSS_MSE) {
+        explainn_set_error("unknown loss kind %d", loss_kind);
+        return EXPLAINN_E_ARG;
+    }
+    return launch_loss(c, loss_kind, logits, targets, B, loss_out, dlogits,
+                       static_cast<hipStream_t>(stream));
+}
+
+extern "C" int explainn_train_step(explainn_ctx* c, const float* x, const float* targets, int B,
+                                   const explainn_params* p, const explainn_grads* g, int loss_kind,
+                                   float dropout_p, uint64_t seed, int freeze_top_n_filters,
+                                   float* logits, float* loss_out, void* stream) {
+    TRY(explainn_forward_train(c, x, B, p, nullptr, dropout_p, seed, logits, stream));
+    TRY(explainn_loss_grad(c, loss_kind, logits, targets, B, loss_out, c->dlogits, stream));
+    TRY(explainn_backward(c, c->dlogits, B, p, g, freeze_top_n_filters, stream));
+    return EXPLAINN_OK;
+}
+
+extern "C" int explainn_input_flags(explainn_ctx* c, int* flags_host, void* stream) {
+    if (!c || !flags_host) { explainn_set_error("null argument"); return EXPLAINN_E_ARG; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemcpyAsync(flags_host, c->flags, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemsetAsync(c->flags, 0, sizeof(int), s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return EXPLAINN_OK;
+}

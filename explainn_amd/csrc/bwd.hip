@@ -1,0 +1,256 @@
+// Backward "small algebra" and the filter-gradient scatter.
+//
+//   mid1      per unit: sum passA's chunk partials; gradients of FC2 weights and BN2 affine
+//             parameters; the two BN2-backward means md2, md2h.
+//   mid2a     per unit: gradient of FC1 weights (BN2 backward folded in through the q covariance)
+//             and the table T[r][w] passB streams.
+//   mid2b     per unit: the n x n matrix M and vector k0' that carry the BN2-backward mean terms
+//             into dq.
+//   conv_bwd  sparse term of the filter gradient: every pooling window sends dy to the one position
+//             that won the max, so dW gets dy added at (base at p*+j, tap j) for the k taps.
+//             Lane = sequence, private LDS accumulators [k][4] per lane (ds_add_f32, conflict-free
+//             by an odd row stride), bases from the 2-bit packed codes with a 64-bit funnel window.
+//   fin_bwd   per unit: BN1 backward closed form -> dW, d gamma1, d beta1.
+#include "common.h"
+
+__global__ __launch_bounds__(128) void mid1_kernel(
+    const float* __restrict__ EQp, const float* __restrict__ Sep, const float* __restrict__ A2,
+    const float* __restrict__ sh2, const float* __restrict__ sig2, const float* __restrict__ fc1_w,
+    const float* __restrict__ fc2_w, const double* __restrict__ qbar, float* __restrict__ EQs,
+    float* __restrict__ md2, float* __restrict__ md2h, float* __restrict__ g_fc2_w,
+    float* __restrict__ g_bn2_w, float* __restrict__ g_bn2_b, float* __restrict__ g_fc1_b, int n,
+    int NS, int B, int ACH, float scale) {
+    const int u = blockIdx.x, r = threadIdx.x;
+    if (r >= FC_H) return;
+    const int ch = u * FC_H + r;
+    double se = 0;
+    for (int c = 0; c < ACH; ++c) se += (double)Sep[((size_t)u * ACH + c) * FC_H + r];
+    double sAE = 0, sVE = 0;
+    const float* v1 = fc1_w + (size_t)ch * n;
+    for (int w = 0; w < n; ++w) {
+        double eq = 0;
+        for (int c = 0; c < ACH; ++c)
+            eq += (double)EQp[(((size_t)u * ACH + c) * FC_H + r) * NS + w];
+        EQs[(size_t)ch * NS + w] = (float)eq;
+        sAE = fma((double)A2[(size_t)ch * NS + w], eq, sAE);
+        sVE = fma((double)v1[w], eq - se * qbar[(size_t)u * NS + w], sVE);
+    }
+    const double sc = (double)scale, v2 = (double)fc2_w[ch], sg = (double)sig2[ch];
+    g_fc2_w[ch] = (float)(sc * (sAE + (double)sh2[ch] * se));
+    const double db2 = sc * v2 * se;
+    const double dg2 = sc * v2 / sg * sVE;
+    g_bn2_b[ch] = (float)db2;
+    g_bn2_w[ch] = (float)dg2;
+    g_fc1_b[ch] = 0.f;
+    md2[ch] = (float)(db2 / (double)B);
+    md2h[ch] = (float)(dg2 / (double)B);
+}
+
+__global__ __launch_bounds__(256) void mid2a_kernel(
+    const float* __restrict__ EQs, const float* __restrict__ A2, const float* __restrict__ sig2,
+    const float* __restrict__ fc1_w, const float* __restrict__ fc2_w, const float* __restrict__ g2,
+    const double* __restrict__ qbar, const float* __restrict__ C, const float* __restrict__ md2,
+    const float* __restrict__ md2h, float* __restrict__ Tt, float* __restrict__ g_fc1_w, int n,
+    int NS, int B, float scale) {
+    const int u = blockIdx.x;
+    const float* Cu = C + (size_t)u * NS * NS;
+    for (int e = threadIdx.x; e < FC_H * NS; e += 256) {
+        const int r = e / NS, w = e % NS, ch = u * FC_H + r;
+        const double sv = (double)scale * (double)fc2_w[ch];
+        Tt[(size_t)ch * NS + w] = (float)(sv * (double)A2[(size_t)ch * NS + w]);
+        if (w < n) {
+            const float* v1 = fc1_w + (size_t)ch * n;
+            double hq = 0;
+            for (int v = 0; v < n; ++v) hq = fma((double)v1[v], (double)Cu[(size_t)v * NS + w], hq);
+            const double sg = (double)sig2[ch];
+            hq *= (double)B / sg;
+            const double val = ((double)g2[ch] / sg) *
+                               (sv * (double)EQs[(size_t)ch * NS + w] -
+                                (double)md2[ch] * (double)B * qbar[(size_t)u * NS + w] -
+                                (double)md2h[ch] * hq);
+            g_fc1_w[(size_t)ch * n + w] = (float)val;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void mid2b_kernel(
+    const float* __restrict__ A2, const float* __restrict__ sig2, const float* __restrict__ fc1_w,
+    const double* __restrict__ qbar, const float* __restrict__ md2, const float* __restrict__ md2h,
+    float* __restrict__ M, float* __restrict__ k0p, int n, int NS) {
+    extern __shared__ float Msm[];            // [n][n]
+    const int u = blockIdx.x;
+    for (int e = threadIdx.x; e < NS * NS; e += 256) {
+        const int v = e / NS, w = e % NS;
+        double acc = 0;
+        if (v < n && w < n) {
+            for (int r = 0; r < FC_H; ++r) {
+                const int ch = u * FC_H + r;
+                acc = fma((double)md2h[ch] / (double)sig2[ch] * (double)fc1_w[(size_t)ch * n + v],
+                          (double)A2[(size_t)ch * NS + w], acc);
+            }
+            Msm[v * n + w] = (float)acc;
+        }
+        M[(size_t)u * NS * NS + e] = (float)acc;
+    }
+    __syncthreads();
+    for (int w = threadIdx.x; w < NS; w += 256) {
+        double k0 = 0;
+        if (w < n) {
+            for (int r = 0; r < FC_H; ++r) {
+                const int ch = u * FC_H + r;
+                k0 = fma((double)A2[(size_t)ch * NS + w], (double)md2[ch], k0);
+            }
+            for (int v = 0; v < n; ++v) k0 -= qbar[(size_t)u * NS + v] * (double)Msm[v * n + w];
+        }
+        k0p[(size_t)u * NS + w] = (float)k0;
+    }
+}
+
+int launch_mid_bwd(explainn_ctx* c, const explainn_params* p, const explainn_grads* g, int B,
+                   hipStream_t s) {
+    hipLaunchKernelGGL(mid1_kernel, dim3(c->U), dim3(128), 0, s, c->EQp, c->Sep, c->A2, c->sh2,
+                       c->sig2, p->fc1_w, p->fc2_w, c->qbar, c->EQs, c->md2, c->md2h, g->fc2_w,
+                       g->bn2_w, g->bn2_b, g->fc1_b, c->n, c->NS, B, c->ACH, c->fwd_scale);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(mid2a_kernel, dim3(c->U), dim3(256), 0, s, c->EQs, c->A2, c->sig2, p->fc1_w,
+                       p->fc2_w, p->bn2_w, c->qbar, c->C, c->md2, c->md2h, c->Tt, g->fc1_w, c->n,
+                       c->NS, B, c->fwd_scale);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(mid2b_kernel, dim3(c->U), dim3(256), (size_t)c->n * c->n * sizeof(float), s,
+                       c->A2, c->sig2, p->fc1_w, c->qbar, c->md2, c->md2h, c->M, c->k0p, c->n,
+                       c->NS);
+    LAUNCH_CHECK();
+    return EXPLAINN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(64) void conv_bwd_kernel(const float* __restrict__ dy,
+                                                      const uint8_t* __restrict__ idx,
+                                                      const uint32_t* __restrict__ pk2,
+                                                      const uint32_t* __restrict__ nmask,
+                                                      float* __restrict__ Dspp, int U, int n,
+                                                      int Bs, int PW, int NW) {
+    extern __shared__ uint32_t smem[];        // pk2 tile [PW][64], nmask tile [NW][64], acc [64][STR]
+    constexpr int STR = 4 * K + 1;            // odd stride: lane rows start on distinct banks
+    uint32_t* pks = smem;
+    uint32_t* nms = smem + (size_t)PW * 64;
+    float* acc = reinterpret_cast<float*>(nms + (size_t)NW * 64);
+    const int lane = threadIdx.x, tile = blockIdx.x, quad = blockIdx.y;
+    const int b = tile * 64 + lane;
+    for (int w = 0; w < PW; ++w) pks[w * 64 + lane] = pk2[(size_t)w * Bs + b];
+    for (int w = 0; w < NW; ++w) nms[w * 64 + lane] = nmask[(size_t)w * Bs + b];
+    float* mine = acc + lane * STR;
+    constexpr uint32_t KMASK = (K >= 32) ? 0xffffffffu : ((1u << K) - 1u);
+    for (int uu = 0; uu < 4; ++uu) {
+        const int u = quad * 4 + uu;
+        if (u >= U) break;
+#pragma unroll
+        for (int i = 0; i < 4 * K; ++i) mine[i] = 0.f;
+        for (int w = 0; w < n; ++w) {
+            const size_t off = ((size_t)u * n + w) * Bs + b;
+            const float dyv = dy[off];
+            const int ps = POOLW * w + (int)idx[off];
+            const int w0 = ps >> 4, sh = (ps & 15) * 2;
+            const uint32_t c0 = pks[w0 * 64 + lane], c1 = pks[(w0 + 1) * 64 + lane],
+                           c2 = pks[(w0 + 2) * 64 + lane];
+            const uint32_t lo = __funnelshift_r(c0, c1, sh), hi = __funnelshift_r(c1, c2, sh);
+            const int n0 = ps >> 5, nsh = ps & 31;
+            const uint32_t nm = __funnelshift_r(nms[n0 * 64 + lane], nms[(n0 + 1) * 64 + lane], nsh) & KMASK;
+            if (__any(nm != 0u)) {
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const uint32_t code = (j < 16 ? (lo >> (2 * j)) : (hi >> (2 * (j - 16)))) & 3u;
+                    if (!((nm >> j) & 1u)) atomicAdd(&mine[j * 4 + code], dyv);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const uint32_t code = (j < 16 ? (lo >> (2 * j)) : (hi >> (2 * (j - 16)))) & 3u;
+                    atomicAdd(&mine[j * 4 + code], dyv);
+                }
+            }
+        }
+        __syncthreads();
+        for (int t = lane; t < 4 * K; t += 64) {
+            const int a = t / K, j = t % K;
+            float s = 0.f;
+            for (int l = 0; l < 64; ++l) s += acc[l * STR + j * 4 + a];
+            Dspp[((size_t)u * (Bs / 64) + tile) * 4 * K + t] = s;
+        }
+        __syncthreads();
+    }
+}
+
+#define KB_DISPATCH(Kv, CALL)                                                                  \
+    switch (Kv) {                                                                              \
+        case 2: { CALL(2); } break;   case 3: { CALL(3); } break;   case 4: { CALL(4); } break;   \
+        case 5: { CALL(5); } break;   case 6: { CALL(6); } break;   case 7: { CALL(7); } break;   \
+        case 8: { CALL(8); } break;   case 9: { CALL(9); } break;   case 10: { CALL(10); } break; \
+        case 11: { CALL(11); } break; case 12: { CALL(12); } break; case 13: { CALL(13); } break; \
+        case 14: { CALL(14); } break; case 15: { CALL(15); } break; case 16: { CALL(16); } break; \
+        case 17: { CALL(17); } break; case 18: { CALL(18); } break; case 19: { CALL(19); } break; \
+        case 20: { CALL(20); } break; case 21: { CALL(21); } break; case 22: { CALL(22); } break; \
+        case 23: { CALL(23); } break; case 24: { CALL(24); } break; case 25: { CALL(25); } break; \
+        case 26: { CALL(26); } break; case 27: { CALL(27); } break; case 28: { CALL(28); } break; \
+        case 29: { CALL(29); } break; case 30: { CALL(30); } break; case 31: { CALL(31); } break; \
+        case 32: { CALL(32); } break;                                                          \
+        default: explainn_set_error("kernel_size %d not instantiated (2..32)", Kv);            \
+                 return EXPLAINN_E_UNSUPPORTED;                                                \
+    }
+
+int launch_conv_bwd(explainn_ctx* c, int B, hipStream_t s) {
+    const dim3 grid((B + 63) / 64, c->Uq);
+    const size_t sm = ((size_t)(c->PW + c->NW) * 64 + (size_t)64 * (4 * c->k + 1)) * sizeof(uint32_t);
+#define CALL(KK)                                                                               \
+    hipLaunchKernelGGL(conv_bwd_kernel<KK>, grid, dim3(64), sm, s, c->dy, c->idx, c->pk2, c->nmask, \
+                       c->Dspp, c->U, c->n, c->Bs, c->PW, c->NW)
+    KB_DISPATCH(c->k, CALL);
+#undef CALL
+    LAUNCH_CHECK();
+    return EXPLAINN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void fin_bwd_kernel(
+    const float* __restrict__ S12p, const float* __restrict__ Dspp, const double* __restrict__ m,
+    const double* __restrict__ Gw, const double* __restrict__ mug, const double* __restrict__ sig1,
+    const float* __restrict__ g1, float* __restrict__ g_conv_w, float* __restrict__ g_conv_b,
+    float* __restrict__ g_bn1_w, float* __restrict__ g_bn1_b, int K4, int Bs, int B, int freeze_n) {
+    const int u = blockIdx.x, tid = threadIdx.x;
+    const int NT = Bs / 64, nt = (B + 63) / 64;
+    double S1 = 0, S2 = 0;
+    for (int t = 0; t < nt; ++t) {
+        S1 += (double)S12p[((size_t)u * NT + t) * 2];
+        S2 += (double)S12p[((size_t)u * NT + t) * 2 + 1];
+    }
+    const double sg = sig1[u], a = (double)g1[u] / sg, mu = mug[u];
+    for (int i = tid; i < K4; i += 128) {
+        double D = 0;
+        for (int t = 0; t < nt; ++t) D += (double)Dspp[((size_t)u * NT + t) * K4 + i];
+        const double val = a * (D - S1 * m[i] - (S2 / sg) * (Gw[(size_t)u * K4 + i] - mu * m[i]));
+        g_conv_w[(size_t)u * K4 + i] = (u < freeze_n) ? 0.f : (float)val;
+    }
+    if (tid == 0) {
+        g_bn1_b[u] = (float)S1;
+        g_bn1_w[u] = (float)S2;
+        g_conv_b[u] = 0.f;
+    }
+}
+
+int launch_fin_bwd(explainn_ctx* c, const explainn_params* p, const explainn_grads* g, int B,
+                   int freeze_n, hipStream_t s) {
+    hipLaunchKernelGGL(fin_bwd_kernel, dim3(c->U), dim3(128), 0, s, c->S12p, c->Dspp, c->m, c->Gw,
+                       c->mug, c->sig1, p->bn1_w, g->conv_w, g->conv_b, g->bn1_w, g->bn1_b, c->K4,
+                       c->Bs, B, freeze_n);
+    LAUNCH_CHECK();
+    return EXPLAINN_OK;
+}
+
+int bwd_configure(explainn_ctx* c) {
+    const size_t sm = (size_t)c->n * c->n * sizeof(float);
+    if (sm > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mid2b_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+    return EXPLAINN_OK;
+}

