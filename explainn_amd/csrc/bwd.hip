@@ -106,8 +106,125 @@ __global__ __launch_bounds__(256) void mid2b_kernel(
     }
 }
 
+
+// Fused mid1+mid2a+mid2b for n <= 72: one 256-thread block per unit with V1, A2, EQ, C and M
+// staged in LDS, so every inner loop reads LDS instead of chasing dependent global loads.
+__global__ __launch_bounds__(256) void mid_fused_kernel(
+    const float* __restrict__ EQp, const float* __restrict__ Sep, const float* __restrict__ A2,
+    const float* __restrict__ sh2, const float* __restrict__ sig2, const float* __restrict__ fc1_w,
+    const float* __restrict__ fc2_w, const float* __restrict__ g2, const double* __restrict__ qbar,
+    const float* __restrict__ C, float* __restrict__ Tt, float* __restrict__ M,
+    float* __restrict__ k0p, float* __restrict__ g_fc2_w, float* __restrict__ g_bn2_w,
+    float* __restrict__ g_bn2_b, float* __restrict__ g_fc1_b, float* __restrict__ g_fc1_w, int n,
+    int NS, int B, int ACH, float scale) {
+    extern __shared__ float fsm[];
+    const int ld = n + 1;
+    float* V1s = fsm;                        // [100][ld]
+    float* A2s = V1s + FC_H * ld;            // [100][ld]
+    float* EQl = A2s + FC_H * ld;            // [100][ld]
+    float* Cs = EQl + FC_H * ld;             // [n][n]
+    float* Ms = Cs + n * n;                  // [n][n]
+    float* qb = Ms + n * n;                  // [n]
+    float* se = qb + n;                      // [100]
+    float* md2s = se + FC_H;                 // [100]
+    float* cfs = md2s + FC_H;                // [100]  md2h / sig2
+    float* md2hs = cfs + FC_H;               // [100]
+    const int u = blockIdx.x, tid = threadIdx.x;
+    for (int e = tid; e < FC_H * n; e += 256) {
+        const int r = e / n, w = e % n;
+        const size_t ch = (size_t)u * FC_H + r;
+        V1s[r * ld + w] = fc1_w[ch * n + w];
+        A2s[r * ld + w] = A2[ch * NS + w];
+        double eq = 0;
+        for (int c = 0; c < ACH; ++c) eq += (double)EQp[(((size_t)u * ACH + c) * FC_H + r) * NS + w];
+        EQl[r * ld + w] = (float)eq;
+    }
+    for (int e = tid; e < n * n; e += 256) Cs[e] = C[(size_t)u * NS * NS + (size_t)(e / n) * NS + (e % n)];
+    for (int w = tid; w < n; w += 256) qb[w] = (float)qbar[(size_t)u * NS + w];
+    for (int r = tid; r < FC_H; r += 256) {
+        double s = 0;
+        for (int c = 0; c < ACH; ++c) s += (double)Sep[((size_t)u * ACH + c) * FC_H + r];
+        se[r] = (float)s;
+    }
+    __syncthreads();
+    const double sc = (double)scale;
+    if (tid < FC_H) {
+        const int r = tid;
+        const size_t ch = (size_t)u * FC_H + r;
+        double sAE = 0, sVE = 0;
+        const double ser = (double)se[r];
+        for (int w = 0; w < n; ++w) {
+            const double eq = (double)EQl[r * ld + w];
+            sAE = fma((double)A2s[r * ld + w], eq, sAE);
+            sVE = fma((double)V1s[r * ld + w], eq - ser * qbar[(size_t)u * NS + w], sVE);
+        }
+        const double v2 = (double)fc2_w[ch], sg = (double)sig2[ch];
+        g_fc2_w[ch] = (float)(sc * (sAE + (double)sh2[ch] * ser));
+        const double db2 = sc * v2 * ser, dg2 = sc * v2 / sg * sVE;
+        g_bn2_b[ch] = (float)db2;
+        g_bn2_w[ch] = (float)dg2;
+        g_fc1_b[ch] = 0.f;
+        md2s[r] = (float)(db2 / (double)B);
+        md2hs[r] = (float)(dg2 / (double)B);
+        cfs[r] = (float)((dg2 / (double)B) / sg);
+    }
+    __syncthreads();
+    for (int e = tid; e < NS * NS; e += 256) {
+        const int v = e / NS, w = e % NS;
+        float acc = 0.f;
+        if (v < n && w < n) {
+            double a = 0;
+            for (int r = 0; r < FC_H; ++r)
+                a = fma((double)(cfs[r] * V1s[r * ld + v]), (double)A2s[r * ld + w], a);
+            acc = (float)a;
+            Ms[v * n + w] = acc;
+        }
+        M[(size_t)u * NS * NS + e] = acc;
+    }
+    for (int e = tid; e < FC_H * NS; e += 256) {
+        const int r = e / NS, w = e % NS;
+        const size_t ch = (size_t)u * FC_H + r;
+        const double sv = sc * (double)fc2_w[ch];
+        float tv = 0.f;
+        if (w < n) {
+            tv = (float)(sv * (double)A2s[r * ld + w]);
+            double hq = 0;
+            for (int v = 0; v < n; ++v) hq = fma((double)V1s[r * ld + v], (double)Cs[v * n + w], hq);
+            const double sg = (double)sig2[ch];
+            hq *= (double)B / sg;
+            const double val = ((double)g2[ch] / sg) *
+                               (sv * (double)EQl[r * ld + w] -
+                                (double)md2s[r] * (double)B * qbar[(size_t)u * NS + w] -
+                                (double)md2hs[r] * hq);
+            g_fc1_w[ch * n + w] = (float)val;
+        }
+        Tt[ch * NS + w] = tv;
+    }
+    __syncthreads();
+    for (int w = tid; w < NS; w += 256) {
+        double k0 = 0;
+        if (w < n) {
+            for (int r = 0; r < FC_H; ++r) k0 = fma((double)A2s[r * ld + w], (double)md2s[r], k0);
+            for (int v = 0; v < n; ++v) k0 -= qbar[(size_t)u * NS + v] * (double)Ms[v * n + w];
+        }
+        k0p[(size_t)u * NS + w] = (float)k0;
+    }
+}
+
+static size_t mid_fused_lds(int n) {
+    return ((size_t)3 * FC_H * (n + 1) + (size_t)2 * n * n + n + 4 * FC_H) * sizeof(float);
+}
+
 int launch_mid_bwd(explainn_ctx* c, const explainn_params* p, const explainn_grads* g, int B,
                    hipStream_t s) {
+    if (c->n <= 72) {
+        hipLaunchKernelGGL(mid_fused_kernel, dim3(c->U), dim3(256), mid_fused_lds(c->n), s, c->EQp,
+                           c->Sep, c->A2, c->sh2, c->sig2, p->fc1_w, p->fc2_w, p->bn2_w, c->qbar,
+                           c->C, c->Tt, c->M, c->k0p, g->fc2_w, g->bn2_w, g->bn2_b, g->fc1_b,
+                           g->fc1_w, c->n, c->NS, B, c->ACH, c->fwd_scale);
+        LAUNCH_CHECK();
+        return EXPLAINN_OK;
+    }
     hipLaunchKernelGGL(mid1_kernel, dim3(c->U), dim3(128), 0, s, c->EQp, c->Sep, c->A2, c->sh2,
                        c->sig2, p->fc1_w, p->fc2_w, c->qbar, c->EQs, c->md2, c->md2h, g->fc2_w,
                        g->bn2_w, g->bn2_b, g->fc1_b, c->n, c->NS, B, c->ACH, c->fwd_scale);
@@ -157,18 +274,23 @@ __global__ __launch_bounds__(64) void conv_bwd_kernel(const float* __restrict__ 
             const uint32_t lo = __funnelshift_r(c0, c1, sh), hi = __funnelshift_r(c1, c2, sh);
             const int n0 = ps >> 5, nsh = ps & 31;
             const uint32_t nm = __funnelshift_r(nms[n0 * 64 + lane], nms[(n0 + 1) * 64 + lane], nsh) & KMASK;
+            // private row: plain read-modify-write (LDS float atomics serialise per lane on
+            // gfx950).  All K reads are issued before the K writes so they pipeline; taps of one
+            // window touch distinct rows j, and the LDS queue keeps windows in order.
+            int slot[K];
+            float cur[K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const uint32_t code = (j < 16 ? (lo >> (2 * j)) : (hi >> (2 * (j - 16)))) & 3u;
+                slot[j] = j * 4 + (int)code;
+                cur[j] = mine[slot[j]];
+            }
             if (__any(nm != 0u)) {
 #pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    const uint32_t code = (j < 16 ? (lo >> (2 * j)) : (hi >> (2 * (j - 16)))) & 3u;
-                    if (!((nm >> j) & 1u)) atomicAdd(&mine[j * 4 + code], dyv);
-                }
+                for (int j = 0; j < K; ++j) mine[slot[j]] = cur[j] + (((nm >> j) & 1u) ? 0.f : dyv);
             } else {
 #pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    const uint32_t code = (j < 16 ? (lo >> (2 * j)) : (hi >> (2 * (j - 16)))) & 3u;
-                    atomicAdd(&mine[j * 4 + code], dyv);
-                }
+                for (int j = 0; j < K; ++j) mine[slot[j]] = cur[j] + dyv;
             }
         }
         __syncthreads();
@@ -252,5 +374,9 @@ int bwd_configure(explainn_ctx* c) {
     if (sm > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mid2b_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+    if (c->n <= 72 && mid_fused_lds(c->n) > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mid_fused_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)mid_fused_lds(c->n)));
     return EXPLAINN_OK;
 }

@@ -40,19 +40,27 @@ __global__ __launch_bounds__(256) void head_fwd_train_kernel(
     }
 }
 
-// logits[b][t] = bf[t] + sum_u Wf[t][u] * o[u][b]
-__global__ __launch_bounds__(256) void logits_kernel(const float* __restrict__ o,
-                                                     const float* __restrict__ Wf,
-                                                     const float* __restrict__ bf,
-                                                     float* __restrict__ logits, int U, int T,
-                                                     int Bs, int B) {
-    const int gid = blockIdx.x * 256 + threadIdx.x;
-    if (gid >= B * T) return;
-    const int t = gid / B, b = gid % B;
-    float acc = bf[t];
+// logits[b][t] = bf[t] + sum_u Wf[t][u] * o[u][b]; one block per (64 sequences, task): its 16
+// waves each sum a slice of the units, then the slices are added in fixed order
+__global__ __launch_bounds__(1024) void logits_kernel(const float* __restrict__ o,
+                                                      const float* __restrict__ Wf,
+                                                      const float* __restrict__ bf,
+                                                      float* __restrict__ logits, int U, int T,
+                                                      int Bs, int B) {
+    __shared__ float part[16][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.x * 64 + lane, t = blockIdx.y;
     const float* wr = Wf + (size_t)t * U;
-    for (int u = 0; u < U; ++u) acc = fmaf(wr[u], o[(size_t)u * Bs + b], acc);
-    logits[(size_t)b * T + t] = acc;
+    float acc = 0.f;
+    for (int u = wv; u < U; u += 16) acc = fmaf(wr[u], o[(size_t)u * Bs + b], acc);
+    part[wv][lane] = acc;
+    __syncthreads();
+    if (wv == 0 && b < B) {
+        float s = bf[t];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += part[i][lane];
+        logits[(size_t)b * T + t] = s;
+    }
 }
 
 // outs[b][u] = o[u][b]   (model.linears(x) output layout, test.py:151)
@@ -73,7 +81,7 @@ int launch_head_fwd(explainn_ctx* c, const explainn_params* p, int B, bool train
         LAUNCH_CHECK();
     }
     if (logits) {
-        hipLaunchKernelGGL(logits_kernel, dim3((B * c->T + 255) / 256), dim3(256), 0, s, c->o,
+        hipLaunchKernelGGL(logits_kernel, dim3((B + 63) / 64, c->T), dim3(1024), 0, s, c->o,
                            p->final_w, p->final_b, logits, c->U, c->T, c->Bs, B);
         LAUNCH_CHECK();
     }

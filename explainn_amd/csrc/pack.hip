@@ -90,12 +90,13 @@ __global__ __launch_bounds__(256) void pair_counts_kernel(const uint8_t* __restr
     if (lane < 16) cnt[(size_t)wid * 16 + lane] = mine;
 }
 
-// one thread per entry of G; row/col index (a,j) -> a*k + j (the flattening of a (4,k) filter)
+// one wavefront per entry of G (lanes stride over the Lo positions, shuffle reduce);
+// row/col index (a,j) -> a*k + j (the flattening of a (4,k) filter)
 __global__ __launch_bounds__(256) void gram_kernel(const int* __restrict__ cnt,
                                                    double* __restrict__ G, double* __restrict__ m,
                                                    int B, int L, int k) {
     const int K4 = 4 * k;
-    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (e >= K4 * K4) return;
     const int row = e / K4, col = e % K4;
     int a = row / k, j = row % k, a2 = col / k, j2 = col % k;
@@ -103,10 +104,14 @@ __global__ __launch_bounds__(256) void gram_kernel(const int* __restrict__ cnt,
     const int d = j2 - j, Lo = L - k + 1;
     const int* src = cnt + ((size_t)d * L + j) * 16 + a * 4 + a2;
     long long s = 0;
-    for (int q = 0; q < Lo; ++q) s += src[(size_t)q * 16];
-    const double v = (double)s / ((double)B * (double)Lo);
-    G[e] = v;
-    if (row == col) m[row] = v;
+    for (int q = lane; q < Lo; q += 64) s += src[(size_t)q * 16];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) {
+        const double v = (double)s / ((double)B * (double)Lo);
+        G[e] = v;
+        if (row == col) m[row] = v;
+    }
 }
 
 int launch_pack(explainn_ctx* c, const float* x, int B, bool counts, hipStream_t s) {
@@ -116,14 +121,14 @@ int launch_pack(explainn_ctx* c, const float* x, int B, bool counts, hipStream_t
     LAUNCH_CHECK();
     if (counts) {
         const int bp = gb * 64;
-        hipLaunchKernelGGL(pack_bits_kernel, dim3((bp + 255) / 256, (c->L + 31) / 32 + 1), dim3(256),
+        hipLaunchKernelGGL(pack_bits_kernel, dim3((bp + 255) / 256, c->NW), dim3(256),
                            0, s, c->codesT, c->pk2, c->nmask, c->L, c->Bs, c->PW, c->NW);
         LAUNCH_CHECK();
         const int waves = c->k * c->L;
         hipLaunchKernelGGL(pair_counts_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, c->codesT,
                            c->cnt, B, c->L, c->k, c->Bs);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(gram_kernel, dim3((c->K4 * c->K4 + 255) / 256), dim3(256), 0, s, c->cnt,
+        hipLaunchKernelGGL(gram_kernel, dim3((c->K4 * c->K4 + 3) / 4), dim3(256), 0, s, c->cnt,
                            c->G, c->m, B, c->L, c->k);
         LAUNCH_CHECK();
     }
