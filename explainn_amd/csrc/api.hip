@@ -46,7 +46,7 @@ void carve(explainn_ctx* c, Carver& cv) {
     cv.take(&c->Wt, (int64_t)c->Uq * c->k * 20);
     cv.take(&c->ext, U4 * n * Bs);
     cv.take(&c->idx, U4 * n * Bs);
-    cv.take(&c->qbw, U * Bs * NS);
+    cv.take(&c->qbw, (U * Bs + 2) * NS);
     cv.take(&c->qs0, U * NS);
     cv.take(&c->qS1p, U * c->QCH * NS);
     cv.take(&c->qS2p, U * c->QCH * NS * NS);
@@ -59,18 +59,18 @@ void carve(explainn_ctx* c, Carver& cv) {
     cv.take(&c->zhat, U * Bs);
     cv.take(&c->o, U * Bs);
     cv.take(&c->sig3, U);
-    cv.take(&c->bits, U * Bs);
-    cv.take(&c->dz, U * Bs);
+    cv.take(&c->bits, U * Bs + 4);
+    cv.take(&c->dz, U * Bs + 4);
     cv.take(&c->EQp, U * c->ACH * FC_H * NS);
     cv.take(&c->Sep, U * c->ACH * FC_H);
     cv.take(&c->EQs, U * FC_H * NS);
     cv.take(&c->md2, U * FC_H);
     cv.take(&c->md2h, U * FC_H);
-    cv.take(&c->Tt, U * FC_H * NS);
-    cv.take(&c->M, U * NS * NS);
+    cv.take(&c->Tt, (U * FC_H + 2) * NS);
+    cv.take(&c->M, (U * NS + 2) * NS);
     cv.take(&c->k0p, U * NS);
     cv.take(&c->dy, U4 * n * Bs);
-    cv.take(&c->S12p, U * (Bs / 64) * 2);
+    cv.take(&c->S12p, U * (Bs / 32) * 2);
     cv.take(&c->Dspp, U * (Bs / 64) * K4);
     cv.take(&c->dlogits, (int64_t)c->maxB * c->T);
     cv.take(&c->flags, 64);
@@ -129,7 +129,7 @@ extern "C" int explainn_create(explainn_ctx** out, int cnn_units, int kernel_siz
     c->U = cnn_units; c->k = kernel_size; c->L = sequence_length; c->T = n_features;
     c->maxB = max_batch; c->device = device;
     c->Lo = Lo; c->n = n; c->U4 = (cnn_units + 3) & ~3; c->Uq = c->U4 / 4;
-    c->NQ = NQ; c->NS = (NQ + 3) & ~3; c->Bs = (max_batch + 63) & ~63; c->K4 = 4 * kernel_size;
+    c->NQ = NQ; c->NS = ns_stride(NQ); c->NX = fcx_stride(NQ); c->Bs = (max_batch + 63) & ~63; c->K4 = 4 * kernel_size;
     c->NW = (sequence_length + 31) / 32 + 2; c->PW = 2 * c->NW;
     {
         int q = (max_batch + 127) / 128;
@@ -166,6 +166,7 @@ extern "C" int explainn_create(explainn_ctx** out, int cnn_units, int kernel_siz
     }
     int rc = prep_configure(c);
     if (rc == EXPLAINN_OK) rc = bwd_configure(c);
+    if (rc == EXPLAINN_OK) rc = fc_configure(c);
     if (rc != EXPLAINN_OK) { hipFree(c->base); delete c; return rc; }
     *out = c;
     return EXPLAINN_OK;

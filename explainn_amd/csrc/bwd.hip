@@ -341,10 +341,11 @@ __global__ __launch_bounds__(128) void fin_bwd_kernel(
     float* __restrict__ g_bn1_w, float* __restrict__ g_bn1_b, int K4, int Bs, int B, int freeze_n) {
     const int u = blockIdx.x, tid = threadIdx.x;
     const int NT = Bs / 64, nt = (B + 63) / 64;
+    const int NT32 = Bs / 32, nt32 = (B + 31) / 32;
     double S1 = 0, S2 = 0;
-    for (int t = 0; t < nt; ++t) {
-        S1 += (double)S12p[((size_t)u * NT + t) * 2];
-        S2 += (double)S12p[((size_t)u * NT + t) * 2 + 1];
+    for (int t = 0; t < nt32; ++t) {
+        S1 += (double)S12p[((size_t)u * NT32 + t) * 2];
+        S2 += (double)S12p[((size_t)u * NT32 + t) * 2 + 1];
     }
     const double sg = sig1[u], a = (double)g1[u] / sg, mu = mug[u];
     for (int i = tid; i < K4; i += 128) {

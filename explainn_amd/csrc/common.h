@@ -52,6 +52,7 @@ struct explainn_ctx {
     double* qbar;         // [U][NS]
     float* C;             // [U][NS][NS]      centred covariance of q over the batch
     float* A2;            // [U][100][NS]     FC1 weights with BN2 folded in
+    int NX;
     float* sh2;           // [U][100]
     float* sig2;          // [U][100]
     float* z;             // [U][Bs]          FC2 output (without its bias)
@@ -69,7 +70,7 @@ struct explainn_ctx {
     float* M;             // [U][NS][NS]
     float* k0p;           // [U][NS]
     float* dy;            // [U4][n][Bs]
-    float* S12p;          // [U][Bs/64][2]
+    float* S12p;          // [U][Bs/32][2]    per 32-sequence tile: sum dy, sum dy*chat
     float* Dspp;          // [U][Bs/64][4k]
     float* dlogits;       // [maxB][T]         (train_step only)
     int* flags;           // [1]
@@ -113,6 +114,7 @@ int launch_fin_bwd(explainn_ctx* c, const explainn_params* p, const explainn_gra
 
 int prep_configure(explainn_ctx* c);
 int bwd_configure(explainn_ctx* c);
+int fc_configure(explainn_ctx* c);
 
 // q = exp(alpha*ext + shift): every consumer must evaluate it identically
 __device__ __forceinline__ float qval(float alpha, float ext, float shift) {
@@ -129,6 +131,19 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
+
+// Row geometry of the scalar-operand tables.  A row of NQ payload floats is cut into NCH chunks of
+// CH floats (CH a multiple of 4, at most 36 so that two chunk buffers fit the SGPR file).
+__host__ __device__ constexpr int chunk_count(int len) { return (len + 35) / 36; }
+__host__ __device__ constexpr int chunk_len(int len) {
+    return (((len + chunk_count(len) - 1) / chunk_count(len)) + 3) & ~3;
+}
+// q / T / M / EQ rows: NQ payload floats
+__host__ __device__ constexpr int ns_stride(int NQ) { return chunk_count(NQ) * chunk_len(NQ); }
+__host__ __device__ constexpr int row_chunk(int NS) { return NS / chunk_count(NS); }
+// fc_fwd rows: [sh2, V2, A2[0..NQ)]
+__host__ __device__ constexpr int fcx_stride(int NQ) { return chunk_count(NQ + 2) * chunk_len(NQ + 2); }
+__host__ __device__ constexpr int fcx_chunk(int NQ) { return chunk_len(NQ + 2); }
 
 // pooled-length buckets with instantiated FC kernels (0 if unsupported)
 static inline int nq_bucket(int n) {

@@ -1,162 +1,231 @@
-// The per-unit two-layer FC (architectures/__init__.py:84-100) and its backward, as three
-// streaming passes whose inner loop is one v_fmac with a SCALAR (SGPR) weight operand:
+// The per-unit two-layer FC (architectures/__init__.py:84-100) and its backward on the exact-fp32
+// matrix cores: v_mfma_f32_32x32x2_f32 is bit-for-bit a k-ordered fmaf chain and runs at the fp32
+// vector rate, but takes both operands from VGPRs -- no scalar/LDS broadcast stream to feed.
+// FC1 is the one dense contraction on this path: per unit (B x n).(n x 100).
 //
-//   fc_fwd   lane = sequence.  q[0..n) of the lane's sequence sits in VGPRs; the BN2-folded FC1
-//            row A2[u][r][:] is wave-uniform and arrives through scalar loads, so
-//            y2 = sh2[r] + sum_w A2[r][w]*q[w] costs n VALU ops and no LDS/vector-memory traffic.
-//            ReLU, dropout, FC2 (z += V2[r]*a) and the 100 "relu'>0 and kept" bits per
-//            (unit, sequence) are produced in the same loop; nothing of size (B,100U) is stored.
-//   passA    lane = hidden channel r.  EQ[r][w] = sum_b e[b,r] q[b,w] with e = dz[b]*bit[b,r];
-//            q[b][:], dz[b] and the bit words are scalars.  Per-chunk partials, fixed-order sum.
-//   passB    lane = sequence.  dq[w] = sum_r e[r] T[r][w] - k0'[w] - sum_v q[v] M[v][w], then
-//            dy = dq*q routed to the pooling argmax, plus the two BN1-backward sums.
+// Fragment convention (cdna_hip_programming.md section 3), lane l, rc = l&31, kk = l>>5:
+//   D[i][j] = sum_k A[i][k] B[k][j] + C[i][j];  A operand = A[rc][2s+kk],  B operand = B[2s+kk][rc]
+//   C/D register g of lane l holds D[(g&3) + 8*(g>>2) + 4*kk][rc].
 //
-// Template parameter NQ >= n is the register-array length (bucketed; weights are zero padded).
+//   fc_fwd   D[r][b] = sum_w A2[r][w] q[b][w] + sh2[r].  A = folded FC1 weights (fragments staged
+//            in LDS once per workgroup), B = q of 32 sequences (registers).  A lane ends up with 16
+//            hidden channels of ITS sequence per r-tile: ReLU, dropout, the FC2 dot product
+//            z += V2[r]*a and the 100 "relu'>0 and kept" bits are all lane-local; the two lane
+//            halves are merged with one cross-half shuffle.  Nothing of size (B,100U) is stored.
+//   passA    D[r][w] = sum_b e[b][r] q[b][w],  e = dz[b]*bit[b][r] built on the fly from the bit
+//            words (A operand), q rows from the sequence-major copy (B operand).
+//   passB    D[w][b] = sum_r T[r][w] e[b][r] - sum_v M[v][w] q[b][v] - k0'[w]; then dy = dq*q and
+//            the two BatchNorm1-backward sums.  A = T and M fragments in LDS.
+//   qmom     (prep.hip) the q second-moment matrix, same instruction.
+//
+// Template parameter NQ >= n (bucketed pooled length); hidden width 100 is padded to 4 tiles of 32.
 #include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
 
-// dmode: 0 no dropout, 1 keep-mask array, 2 counter-based generator
-template <int NQ, bool TRAIN>
-__global__ __launch_bounds__(64) void fc_fwd_kernel(
+#define FC_RT 4                      // r-tiles of 32 covering the 100 hidden channels
+#define FC_BTW 2                     // 32-sequence tiles per wavefront in fc_fwd / passB
+
+// MODE: 0 eval, 1 train without dropout, 2 train + counter-based generator, 3 train + keep-mask
+template <int NQ, int MODE>
+__global__ __launch_bounds__(256) void fc_fwd_kernel(
     const float* __restrict__ ext, const float* __restrict__ alpha,
     const float* __restrict__ shift, const float* __restrict__ A2, const float* __restrict__ sh2,
     const float* __restrict__ V2, uint4* __restrict__ bits, float* __restrict__ zout,
-    const uint8_t* __restrict__ keep_mask, int dmode, uint32_t thresh16, float scale,
-    uint32_t seed_lo, uint32_t seed_hi, const float* __restrict__ c2,
-    const float* __restrict__ g3, const float* __restrict__ b3, const float* __restrict__ rm3,
-    const float* __restrict__ rv3, float* __restrict__ oout, int n, int Bs, int B, int U) {
-    constexpr int NS = (NQ + 3) & ~3;
-    const int u = blockIdx.y, lane = threadIdx.x;
-    const int b = blockIdx.x * 64 + lane;
+    const uint8_t* __restrict__ keep_mask, uint32_t thresh16, float scale, uint32_t seed_lo,
+    uint32_t seed_hi, const float* __restrict__ c2, const float* __restrict__ g3,
+    const float* __restrict__ b3, const float* __restrict__ rm3, const float* __restrict__ rv3,
+    float* __restrict__ oout, int n, int Bs, int B, int U) {
+    constexpr int NS = ns_stride(NQ), NKS = (NQ + 1) / 2;
+    constexpr bool TRAIN = MODE != 0;
+    __shared__ float Af[FC_RT * NKS * 64];
+    __shared__ __attribute__((aligned(16))) float sh2s[128];
+    __shared__ __attribute__((aligned(16))) float v2s[128];
+    const int u = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rc = lane & 31, kk = lane >> 5;
+    // stage the A fragments: Af[(t*NKS+s)*64 + l] = A2[32t + (l&31)][2s + (l>>5)]
+    for (int i = tid; i < FC_RT * NKS * 64; i += 256) {
+        const int l = i & 63, s = (i >> 6) % NKS, t = (i >> 6) / NKS;
+        const int r = 32 * t + (l & 31), w = 2 * s + (l >> 5);
+        Af[i] = (r < FC_H && w < n) ? A2[((size_t)u * FC_H + r) * NS + w] : 0.f;
+    }
+    if (tid < 128) {
+        sh2s[tid] = tid < FC_H ? sh2[(size_t)u * FC_H + tid] : 0.f;
+        v2s[tid] = tid < FC_H ? V2[(size_t)u * FC_H + tid] : 0.f;
+    }
+    __syncthreads();
     const float a1 = alpha[u], s1 = shift[u];
-    float q[NQ];
+    for (int it = 0; it < FC_BTW; ++it) {
+        const int bt = (blockIdx.x * 4 + wave) * FC_BTW + it;
+        const int b = bt * 32 + rc;
+        if (bt * 32 >= B) break;                       // wave-uniform
+        float qf[NKS];
 #pragma unroll
-    for (int w = 0; w < NQ; ++w)
-        q[w] = (w < n) ? qval(a1, ext[((size_t)u * n + w) * Bs + b], s1) : 0.f;
-    const float* Au = A2 + (size_t)u * FC_H * NS;
-    const float* shu = sh2 + (size_t)u * FC_H;
-    const float* V2u = V2 + (size_t)u * FC_H;
-    uint32_t rs = 0;
-    if (TRAIN && dmode == 2)
-        rs = mix32(mix32(seed_lo ^ (uint32_t)b * 0x9E3779B9U) ^ mix32(seed_hi + (uint32_t)u)) | 1u;
-    const uint8_t* km = (TRAIN && dmode == 1) ? keep_mask + (size_t)min(b, B - 1) * FC_H * U + (size_t)u * FC_H
-                                              : nullptr;
-    float zacc = 0.f;
-    uint32_t words[4] = {0u, 0u, 0u, 0u};
+        for (int s = 0; s < NKS; ++s) {
+            const int w = 2 * s + kk;
+            qf[s] = (w < n) ? qval(a1, ext[((size_t)u * n + w) * Bs + b], s1) : 0.f;
+        }
+        uint32_t rs = 0;
+        if (MODE == 2)
+            rs = mix32(mix32(seed_lo ^ (uint32_t)(2 * b + kk) * 0x9E3779B9U) ^
+                       mix32(seed_hi + (uint32_t)u)) | 1u;
+        const uint8_t* km = (MODE == 3) ? keep_mask + (size_t)min(b, B - 1) * FC_H * U + (size_t)u * FC_H
+                                        : nullptr;
+        float zp = 0.f;
+        uint32_t words[FC_RT];
 #pragma unroll
-    for (int wd = 0; wd < 4; ++wd) {
-        uint32_t cur = 0u;
-        const int cntr = (wd == 3) ? (FC_H - 96) : 32;
-#pragma unroll 4
-        for (int rr = 0; rr < cntr; ++rr) {
-            const int r = wd * 32 + rr;
-            const float* Ar = Au + (size_t)r * NS;
-            float y = shu[r];
+        for (int t = 0; t < FC_RT; ++t) {
+            f32x16 acc;
 #pragma unroll
-            for (int w = 0; w < NQ; ++w) y = fmaf(Ar[w], q[w], y);
-            bool pos = y > 0.f;
-            if (TRAIN) {
-                if (dmode == 2) {
-                    uint32_t rnd;
-                    if ((rr & 1) == 0) { rs ^= rs << 13; rs ^= rs >> 17; rs ^= rs << 5; rnd = rs & 0xffffU; }
-                    else rnd = rs >> 16;
-                    pos = pos && (rnd >= thresh16);
-                } else if (dmode == 1) {
-                    pos = pos && (km[r] != 0);
+            for (int g = 0; g < 4; ++g) {
+                const float4 v = *reinterpret_cast<const float4*>(&sh2s[32 * t + 8 * g + 4 * kk]);
+                acc[4 * g] = v.x; acc[4 * g + 1] = v.y; acc[4 * g + 2] = v.z; acc[4 * g + 3] = v.w;
+            }
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) acc = MFMA32(Af[(t * NKS + s) * 64 + lane], qf[s], acc);
+            uint32_t word = 0u;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 v2 = *reinterpret_cast<const float4*>(&v2s[32 * t + 8 * g + 4 * kk]);
+                const float v2a[4] = {v2.x, v2.y, v2.z, v2.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float y = acc[4 * g + j];
+                    bool pos = y > 0.f;
+                    if (MODE == 2) {
+                        uint32_t rnd;
+                        if ((j & 1) == 0) { rs ^= rs << 13; rs ^= rs >> 17; rs ^= rs << 5; rnd = rs & 0xffffU; }
+                        else rnd = rs >> 16;
+                        pos = pos && (rnd >= thresh16);
+                    } else if (MODE == 3) {
+                        const int r = 32 * t + 8 * g + 4 * kk + j;
+                        pos = pos && (km[r < FC_H ? r : 0] != 0);
+                    }
+                    const float av = pos ? y * scale : 0.f;
+                    zp = fmaf(v2a[j], av, zp);
+                    word |= (pos ? 1u : 0u) << (8 * g + 4 * kk + j);
                 }
             }
-            const float av = pos ? y * scale : 0.f;
-            zacc = fmaf(V2u[r], av, zacc);
-            cur |= (pos ? 1u : 0u) << rr;
+            words[t] = word;
         }
-        words[wd] = cur;
-    }
-    if (TRAIN) {
-        zout[(size_t)u * Bs + b] = zacc;
-        bits[(size_t)u * Bs + b] = make_uint4(words[0], words[1], words[2], words[3]);
-    } else {
-        const float inv = g3[u] / sqrtf(rv3[u] + (float)BN_EPS_D);
-        const float y3 = fmaf(inv, zacc + c2[u] - rm3[u], b3[u]);
-        oout[(size_t)u * Bs + b] = fmaxf(y3, 0.f);
+        zp += __shfl_xor(zp, 32, 64);
+#pragma unroll
+        for (int t = 0; t < FC_RT; ++t) words[t] |= __shfl_xor(words[t], 32, 64);
+        if (kk == 0) {
+            if (TRAIN) {
+                zout[(size_t)u * Bs + b] = zp;
+                bits[(size_t)u * Bs + b] = make_uint4(words[0], words[1], words[2], words[3]);
+            } else {
+                const float inv = g3[u] / sqrtf(rv3[u] + (float)BN_EPS_D);
+                const float y3 = fmaf(inv, zp + c2[u] - rm3[u], b3[u]);
+                oout[(size_t)u * Bs + b] = fmaxf(y3, 0.f);
+            }
+        }
     }
 }
 
 int launch_fc_fwd(explainn_ctx* c, const explainn_params* p, int B, bool train,
                   const uint8_t* keep_mask, float drop_p, uint64_t seed, hipStream_t s) {
-    const dim3 grid((B + 63) / 64, c->U);
-    int dmode = 0;
+    const int tiles = (B + 31) / 32;
+    const dim3 grid((tiles + 4 * FC_BTW - 1) / (4 * FC_BTW), c->U);
+    int mode = train ? 1 : 0;
     float scale = 1.f;
     uint32_t thresh = 0;
     if (train && drop_p > 0.f) {
-        dmode = keep_mask ? 1 : 2;
+        mode = keep_mask ? 3 : 2;
         scale = 1.0f / (1.0f - drop_p);
         thresh = (uint32_t)(drop_p * 65536.0 + 0.5);
     }
-    if (train) { c->fwd_drop = dmode != 0; c->fwd_scale = scale; }
-#define CALL(N)                                                                                   \
-    if (train)                                                                                    \
-        hipLaunchKernelGGL((fc_fwd_kernel<N, true>), grid, dim3(64), 0, s, c->ext, c->alpha,      \
-                           c->shift, c->A2, c->sh2, p->fc2_w, c->bits, c->z, keep_mask, dmode,    \
-                           thresh, scale, (uint32_t)seed, (uint32_t)(seed >> 32), p->fc2_b,       \
-                           p->bn3_w, p->bn3_b, p->bn3_rm, p->bn3_rv, c->o, c->n, c->Bs, B, c->U);  \
-    else                                                                                          \
-        hipLaunchKernelGGL((fc_fwd_kernel<N, false>), grid, dim3(64), 0, s, c->ext, c->alpha,     \
-                           c->shift, c->A2, c->sh2, p->fc2_w, c->bits, c->z, keep_mask, dmode,    \
-                           thresh, scale, (uint32_t)seed, (uint32_t)(seed >> 32), p->fc2_b,       \
-                           p->bn3_w, p->bn3_b, p->bn3_rm, p->bn3_rv, c->o, c->n, c->Bs, B, c->U)
+    if (train) { c->fwd_drop = mode > 1; c->fwd_scale = scale; }
+#define ARGS c->ext, c->alpha, c->shift, c->A2, c->sh2, p->fc2_w, c->bits, c->z, keep_mask, thresh, \
+             scale, (uint32_t)seed, (uint32_t)(seed >> 32), p->fc2_b, p->bn3_w, p->bn3_b,          \
+             p->bn3_rm, p->bn3_rv, c->o, c->n, c->Bs, B, c->U
+#define CALL(N)                                                                                    \
+    switch (mode) {                                                                                \
+        case 0: hipLaunchKernelGGL((fc_fwd_kernel<N, 0>), grid, dim3(256), 0, s, ARGS); break;     \
+        case 1: hipLaunchKernelGGL((fc_fwd_kernel<N, 1>), grid, dim3(256), 0, s, ARGS); break;     \
+        case 2: hipLaunchKernelGGL((fc_fwd_kernel<N, 2>), grid, dim3(256), 0, s, ARGS); break;     \
+        default: hipLaunchKernelGGL((fc_fwd_kernel<N, 3>), grid, dim3(256), 0, s, ARGS); break;    \
+    }
     NQ_DISPATCH(c->NQ, CALL);
 #undef CALL
+#undef ARGS
     LAUNCH_CHECK();
     return EXPLAINN_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
+// passA: one wavefront per (unit, batch chunk); K dimension = sequences, two per MFMA
+// ---------------------------------------------------------------------------------------------
 template <int NQ>
-__global__ __launch_bounds__(128) void passA_kernel(const float* __restrict__ qbw,
-                                                    const float* __restrict__ dz,
-                                                    const uint4* __restrict__ bits,
-                                                    float* __restrict__ EQp,
-                                                    float* __restrict__ Sep, int Bs, int B,
-                                                    int ACH) {
-    constexpr int NS = (NQ + 3) & ~3;
-    const int u = blockIdx.y, ch = blockIdx.x, r = threadIdx.x;
-    const int per = (B + ACH - 1) / ACH;
+__global__ __launch_bounds__(64) void passA_kernel(const float* __restrict__ qbw,
+                                                   const float* __restrict__ dz,
+                                                   const uint4* __restrict__ bits,
+                                                   float* __restrict__ EQp,
+                                                   float* __restrict__ Sep, int n, int Bs, int B,
+                                                   int ACH) {
+    constexpr int NS = ns_stride(NQ), NWT = (NQ + 31) / 32;
+    const int u = blockIdx.y, ch = blockIdx.x, lane = threadIdx.x;
+    const int rc = lane & 31, kk = lane >> 5;
+    const int per = (((B + ACH - 1) / ACH) + 1) & ~1;          // even: whole k-steps
     const int bbeg = ch * per, bend = min(B, bbeg + per);
-    const int wsel = r >> 5, bsh = r & 31;
-    float acc[NQ];
-#pragma unroll
-    for (int w = 0; w < NQ; ++w) acc[w] = 0.f;
-    float se = 0.f;
     const float* dzu = dz + (size_t)u * Bs;
     const uint4* bu = bits + (size_t)u * Bs;
+    const float* qu = qbw + (size_t)u * Bs * NS;
+    float se[FC_RT] = {0.f, 0.f, 0.f, 0.f};
+    for (int wt = 0; wt < NWT; ++wt) {
+        const int w = wt * 32 + rc;
+        f32x16 acc[FC_RT];
+#pragma unroll
+        for (int t = 0; t < FC_RT; ++t)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[t][g] = 0.f;
 #pragma unroll 2
-    for (int b = bbeg; b < bend; ++b) {
-        const float dzb = dzu[b];                       // scalar
-        const uint4 wv = bu[b];                         // scalar, 16 B
-        const uint32_t myw = wsel == 0 ? wv.x : (wsel == 1 ? wv.y : (wsel == 2 ? wv.z : wv.w));
-        const float e = ((myw >> bsh) & 1u) ? dzb : 0.f;
-        se += e;
-        const float* row = qbw + ((size_t)u * Bs + b) * NS;   // scalar row
+        for (int b0 = bbeg; b0 < bend; b0 += 2) {
+            const int b = b0 + kk;
+            const bool live = b < bend;
+            const int bc = live ? b : bbeg;
+            const float qv = (live && w < NS) ? qu[(size_t)bc * NS + w] : 0.f;
+            const float dzb = live ? dzu[bc] : 0.f;
+            const uint4 wv = bu[bc];
+            const uint32_t wds[FC_RT] = {wv.x, wv.y, wv.z, wv.w};
 #pragma unroll
-        for (int w = 0; w < NQ; ++w) acc[w] = fmaf(e, row[w], acc[w]);
+            for (int t = 0; t < FC_RT; ++t) {
+                const float e = ((wds[t] >> rc) & 1u) ? dzb : 0.f;
+                if (wt == 0) se[t] += e;
+                acc[t] = MFMA32(e, qv, acc[t]);
+            }
+        }
+        // D[r][w]: lane holds column w = wt*32+rc, rows r = 32t + (g&3) + 8(g>>2) + 4kk
+        if (w < NS) {
+#pragma unroll
+            for (int t = 0; t < FC_RT; ++t)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int r = 32 * t + (g & 3) + 8 * (g >> 2) + 4 * kk;
+                    if (r < FC_H) EQp[(((size_t)u * ACH + ch) * FC_H + r) * NS + w] = acc[t][g];
+                }
+        }
     }
-    if (r < FC_H) {
-        float* dst = EQp + (((size_t)u * ACH + ch) * FC_H + r) * NS;
 #pragma unroll
-        for (int w = 0; w < NS; ++w) dst[w] = (w < NQ) ? acc[w < NQ ? w : 0] : 0.f;
-        Sep[((size_t)u * ACH + ch) * FC_H + r] = se;
+    for (int t = 0; t < FC_RT; ++t) {
+        const float s = se[t] + __shfl_xor(se[t], 32, 64);
+        const int r = 32 * t + rc;
+        if (kk == 0 && r < FC_H) Sep[((size_t)u * ACH + ch) * FC_H + r] = s;
     }
 }
 
 int launch_passA(explainn_ctx* c, int B, hipStream_t s) {
     const dim3 grid(c->ACH, c->U);
-#define CALL(N)                                                                            \
-    hipLaunchKernelGGL(passA_kernel<N>, grid, dim3(128), 0, s, c->qbw, c->dz, c->bits, c->EQp, \
-                       c->Sep, c->Bs, B, c->ACH)
+#define CALL(N)                                                                           \
+    hipLaunchKernelGGL(passA_kernel<N>, grid, dim3(64), 0, s, c->qbw, c->dz, c->bits, c->EQp, \
+                       c->Sep, c->n, c->Bs, B, c->ACH)
     NQ_DISPATCH(c->NQ, CALL);
 #undef CALL
     LAUNCH_CHECK();
@@ -164,79 +233,117 @@ int launch_passA(explainn_ctx* c, int B, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// passB: workgroup = 4 wavefronts of one unit; T and M fragments staged in LDS
+// ---------------------------------------------------------------------------------------------
 template <int NQ>
-__global__ __launch_bounds__(64) void passB_kernel(
+__global__ __launch_bounds__(256) void passB_kernel(
     const float* __restrict__ ext, const float* __restrict__ alpha,
     const float* __restrict__ shift, const float* __restrict__ dz, const uint4* __restrict__ bits,
     const float* __restrict__ Tt, const float* __restrict__ M, const float* __restrict__ k0p,
     const double* __restrict__ mug, const double* __restrict__ sig1, float* __restrict__ dy,
     float* __restrict__ S12p, int n, int Bs, int B) {
-    constexpr int NS = (NQ + 3) & ~3;
-    const int u = blockIdx.y, lane = threadIdx.x;
-    const int b = blockIdx.x * 64 + lane;
+    constexpr int NS = ns_stride(NQ), NKS = (NQ + 1) / 2, NWT = (NQ + 31) / 32, RKS = FC_H / 2;
+    extern __shared__ __attribute__((aligned(16))) float smemB[];
+    float* Tf = smemB;                                 // [NWT][RKS][64]
+    float* Mf = Tf + NWT * RKS * 64;                   // [NWT][NKS][64]
+    float* k0s = Mf + NWT * NKS * 64;                  // [NWT*32]
+    const int u = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rc = lane & 31, kk = lane >> 5;
+    // A fragments: Tf[(wt*RKS+s)*64+l] = T[r=2s+(l>>5)][w=wt*32+(l&31)],  Mf likewise over v
+    for (int i = tid; i < NWT * RKS * 64; i += 256) {
+        const int l = i & 63, s = (i >> 6) % RKS, wt = (i >> 6) / RKS;
+        const int r = 2 * s + (l >> 5), w = wt * 32 + (l & 31);
+        Tf[i] = (w < NS) ? Tt[((size_t)u * FC_H + r) * NS + w] : 0.f;
+    }
+    for (int i = tid; i < NWT * NKS * 64; i += 256) {
+        const int l = i & 63, s = (i >> 6) % NKS, wt = (i >> 6) / NKS;
+        const int v = 2 * s + (l >> 5), w = wt * 32 + (l & 31);
+        Mf[i] = (w < NS && v < NS) ? M[((size_t)u * NS + v) * NS + w] : 0.f;
+    }
+    for (int i = tid; i < NWT * 32; i += 256) k0s[i] = (i < NS) ? k0p[(size_t)u * NS + i] : 0.f;
+    __syncthreads();
     const float a1 = alpha[u], s1 = shift[u];
-    float q[NQ], acc[NQ];
-    const float* k0u = k0p + (size_t)u * NS;
-#pragma unroll
-    for (int w = 0; w < NQ; ++w) {
-        q[w] = (w < n) ? qval(a1, ext[((size_t)u * n + w) * Bs + b], s1) : 0.f;
-        acc[w] = -k0u[w];
-    }
-    const uint4 wv = bits[(size_t)u * Bs + b];
-    const float dzb = dz[(size_t)u * Bs + b];
-    const uint32_t words[4] = {wv.x, wv.y, wv.z, wv.w};
-    const float* Tu = Tt + (size_t)u * FC_H * NS;
-#pragma unroll
-    for (int wd = 0; wd < 4; ++wd) {
-        const int cntr = (wd == 3) ? (FC_H - 96) : 32;
-#pragma unroll 4
-        for (int rr = 0; rr < cntr; ++rr) {
-            const float e = ((words[wd] >> rr) & 1u) ? dzb : 0.f;
-            const float* Tr = Tu + (size_t)(wd * 32 + rr) * NS;
-#pragma unroll
-            for (int w = 0; w < NQ; ++w) acc[w] = fmaf(e, Tr[w], acc[w]);
-        }
-    }
-    const float* Mu = M + (size_t)u * NS * NS;
-#pragma unroll 2
-    for (int v = 0; v < n; ++v) {
-        // q[v] with a runtime (uniform) v: select through a static unrolled chain is costly, so
-        // recompute it from ext (L2-resident) instead
-        const float nq = -qval(a1, ext[((size_t)u * n + v) * Bs + b], s1);
-        const float* Mr = Mu + (size_t)v * NS;
-#pragma unroll
-        for (int w = 0; w < NQ; ++w) acc[w] = fmaf(nq, Mr[w], acc[w]);
-    }
     const float mu = (float)mug[u];
     const float isg = (float)(1.0 / sig1[u]);
-    float sA = 0.f, sB = 0.f;
-    const bool live = b < B;
+    for (int it = 0; it < FC_BTW; ++it) {
+        const int bt = (blockIdx.x * 4 + wave) * FC_BTW + it;
+        if (bt * 32 >= B) break;                       // wave-uniform
+        const int b = bt * 32 + rc;
+        const bool live = b < B;
+        float nqf[NKS];
 #pragma unroll
-    for (int w = 0; w < NQ; ++w) {
-        if (w < n) {
-            const float dyv = live ? acc[w] * q[w] : 0.f;
-            const float ch = (ext[((size_t)u * n + w) * Bs + b] - mu) * isg;
-            sA += dyv;
-            sB = fmaf(dyv, ch, sB);
-            dy[((size_t)u * n + w) * Bs + b] = dyv;
+        for (int s = 0; s < NKS; ++s) {
+            const int w = 2 * s + kk;
+            nqf[s] = (w < n) ? -qval(a1, ext[((size_t)u * n + w) * Bs + b], s1) : 0.f;
         }
-    }
-    sA = wave_sum(sA);
-    sB = wave_sum(sB);
-    if (lane == 0) {
-        float* d = S12p + ((size_t)u * (Bs / 64) + blockIdx.x) * 2;
-        d[0] = sA; d[1] = sB;
+        const uint4 wv = bits[(size_t)u * Bs + b];
+        const float dzb = dz[(size_t)u * Bs + b];
+        const uint32_t wds[4] = {wv.x, wv.y, wv.z, wv.w};
+        float sA = 0.f, sB = 0.f;
+#pragma unroll
+        for (int wt = 0; wt < NWT; ++wt) {
+            f32x16 acc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 v = *reinterpret_cast<const float4*>(&k0s[wt * 32 + 8 * g + 4 * kk]);
+                acc[4 * g] = -v.x; acc[4 * g + 1] = -v.y; acc[4 * g + 2] = -v.z; acc[4 * g + 3] = -v.w;
+            }
+#pragma unroll
+            for (int s = 0; s < RKS; ++s) {
+                const float e = (((wds[s >> 4] >> ((2 * s) & 31)) >> kk) & 1u) ? dzb : 0.f;
+                acc = MFMA32(Tf[(wt * RKS + s) * 64 + lane], e, acc);
+            }
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) acc = MFMA32(Mf[(wt * NKS + s) * 64 + lane], nqf[s], acc);
+            // D[w][b]: lane holds its sequence b, rows w = wt*32 + (g&3) + 8(g>>2) + 4kk
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int w = wt * 32 + (g & 3) + 8 * (g >> 2) + 4 * kk;
+                if (w < n) {
+                    const float ex = ext[((size_t)u * n + w) * Bs + b];
+                    const float qv = qval(a1, ex, s1);
+                    const float dyv = live ? acc[g] * qv : 0.f;
+                    sA += dyv;
+                    sB = fmaf(dyv, (ex - mu) * isg, sB);
+                    dy[((size_t)u * n + w) * Bs + b] = dyv;
+                }
+            }
+        }
+        sA = wave_sum(sA);
+        sB = wave_sum(sB);
+        if (lane == 0) {
+            float* d = S12p + ((size_t)u * (Bs / 32) + bt) * 2;
+            d[0] = sA; d[1] = sB;
+        }
     }
 }
 
+template <int NQ>
+static size_t passB_lds() {
+    constexpr int NKS = (NQ + 1) / 2, NWT = (NQ + 31) / 32;
+    return (size_t)(NWT * (FC_H / 2) * 64 + NWT * NKS * 64 + NWT * 32) * sizeof(float);
+}
+
 int launch_passB(explainn_ctx* c, int B, hipStream_t s) {
-    const dim3 grid((B + 63) / 64, c->U);
-#define CALL(N)                                                                                 \
-    hipLaunchKernelGGL(passB_kernel<N>, grid, dim3(64), 0, s, c->ext, c->alpha, c->shift, c->dz, \
-                       c->bits, c->Tt, c->M, c->k0p, c->mug, c->sig1, c->dy, c->S12p, c->n,     \
-                       c->Bs, B)
+    const int tiles = (B + 31) / 32;
+    const dim3 grid((tiles + 4 * FC_BTW - 1) / (4 * FC_BTW), c->U);
+#define CALL(N)                                                                                  \
+    hipLaunchKernelGGL(passB_kernel<N>, grid, dim3(256), passB_lds<N>(), s, c->ext, c->alpha,    \
+                       c->shift, c->dz, c->bits, c->Tt, c->M, c->k0p, c->mug, c->sig1, c->dy,    \
+                       c->S12p, c->n, c->Bs, B)
     NQ_DISPATCH(c->NQ, CALL);
 #undef CALL
     LAUNCH_CHECK();
+    return EXPLAINN_OK;
+}
+
+int fc_configure(explainn_ctx* c) {
+#define CALL(N)                                                                              \
+    if (passB_lds<N>() > 48 * 1024)                                                          \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&passB_kernel<N>),          \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,              \
+                                    (int)passB_lds<N>()))
+    NQ_DISPATCH(c->NQ, CALL);
+#undef CALL
     return EXPLAINN_OK;
 }

@@ -119,32 +119,50 @@ __global__ __launch_bounds__(64) void qtrans_kernel(const float* __restrict__ ex
 // qmom: per (unit, batch chunk): S1[w'] = sum_b (q[b,w']-s[w']),  S2r[w][w'] = sum_b q[b,w]*(q[b,w']-s[w'])
 // lane = w'; q[b,w] is a scalar (uniform) operand
 // ---------------------------------------------------------------------------------------------
+typedef float f32x16q __attribute__((ext_vector_type(16)));
+
+// One wavefront per (unit, batch chunk) on the exact-fp32 matrix core: S2r = Q' (Q - s), with the
+// sequence index as the K dimension (two sequences per v_mfma_f32_32x32x2_f32).
 template <int NQ>
-__global__ __launch_bounds__(((NQ + 63) / 64) * 64) void qmom_kernel(
+__global__ __launch_bounds__(64) void qmom_kernel(
     const float* __restrict__ qbw, const float* __restrict__ qs0, float* __restrict__ S1p,
     float* __restrict__ S2p, int n, int Bs, int B, int QCH) {
-    constexpr int NS = (NQ + 3) & ~3;
-    const int u = blockIdx.y, ch = blockIdx.x, wp = threadIdx.x;
-    const int per = (B + QCH - 1) / QCH;
+    constexpr int NS = ns_stride(NQ), NWT = (NQ + 31) / 32;
+    const int u = blockIdx.y, ch = blockIdx.x, lane = threadIdx.x;
+    const int rc = lane & 31, kk = lane >> 5;
+    const int per = (((B + QCH - 1) / QCH) + 1) & ~1;
     const int bbeg = ch * per, bend = min(B, bbeg + per);
-    const bool act = wp < n;
-    const float s = act ? qs0[(size_t)u * NS + wp] : 0.f;
-    float acc[NQ];
+    const float* qu = qbw + (size_t)u * Bs * NS;
+    for (int wt = 0; wt < NWT; ++wt) {
+        for (int wt2 = 0; wt2 < NWT; ++wt2) {
+            const int wA = wt * 32 + rc, wB = wt2 * 32 + rc;
+            const float sB = (wB < n) ? qs0[(size_t)u * NS + wB] : 0.f;
+            f32x16q acc;
 #pragma unroll
-    for (int w = 0; w < NQ; ++w) acc[w] = 0.f;
-    float s1 = 0.f;
-    for (int b = bbeg; b < bend; ++b) {
-        const float* row = qbw + ((size_t)u * Bs + b) * NS;     // uniform address
-        const float dq = act ? row[wp] - s : 0.f;
-        s1 += dq;
+            for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+            float s1 = 0.f;
+#pragma unroll 4
+            for (int b0 = bbeg; b0 < bend; b0 += 2) {
+                const int b = b0 + kk;
+                const bool live = b < bend;
+                const size_t row = (size_t)(live ? b : bbeg) * NS;
+                const float a = (live && wA < NS) ? qu[row + wA] : 0.f;
+                const float bq = (live && wB < n) ? qu[row + wB] - sB : 0.f;
+                s1 += bq;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc, 0, 0, 0);
+            }
+            if (wB < NS) {
 #pragma unroll
-        for (int w = 0; w < NQ; ++w) acc[w] = fmaf(row[w], dq, acc[w]);
-    }
-    if (wp < NS) {
-        S1p[((size_t)u * QCH + ch) * NS + wp] = s1;
-        float* dst = S2p + ((size_t)u * QCH + ch) * NS * NS + wp;
-#pragma unroll
-        for (int w = 0; w < NQ; ++w) dst[(size_t)w * NS] = acc[w];
+                for (int g = 0; g < 16; ++g) {
+                    const int w = wt * 32 + (g & 3) + 8 * (g >> 2) + 4 * kk;
+                    if (w < NS) S2p[(((size_t)u * QCH + ch) * NS + w) * NS + wB] = acc[g];
+                }
+            }
+            if (wt == 0) {
+                s1 += __shfl_xor(s1, 32, 64);
+                if (kk == 0 && wB < NS) S1p[((size_t)u * QCH + ch) * NS + wB] = s1;
+            }
+        }
     }
 }
 
@@ -154,7 +172,7 @@ int launch_qmoments(explainn_ctx* c, int B, hipStream_t s) {
                        c->ext, c->alpha, c->shift, c->qbw, c->qs0, c->n, c->NS, c->Bs, B);
     LAUNCH_CHECK();
 #define CALL(N)                                                                                  \
-    hipLaunchKernelGGL(qmom_kernel<N>, dim3(c->QCH, c->U), dim3(((N + 63) / 64) * 64), 0, s,     \
+    hipLaunchKernelGGL(qmom_kernel<N>, dim3(c->QCH, c->U), dim3(64), 0, s,     \
                        c->qbw, c->qs0, c->qS1p, c->qS2p, c->n, c->Bs, B, c->QCH)
     NQ_DISPATCH(c->NQ, CALL);
 #undef CALL
@@ -183,7 +201,8 @@ __global__ __launch_bounds__(256) void prep2_kernel(
         for (int e = tid; e < FC_H * NS; e += 256) {
             const int r = e / NS, w = e % NS, ch = u * FC_H + r;
             const double inv = (double)g2[ch] / sqrt((double)rv2[ch] + BN_EPS_D);
-            A2[(size_t)ch * NS + w] = (w < n) ? (float)(inv * (double)fc1_w[(size_t)ch * n + w]) : 0.f;
+            const float a = (w < n) ? (float)(inv * (double)fc1_w[(size_t)ch * n + w]) : 0.f;
+            A2[(size_t)ch * NS + w] = a;
             if (w == 0)
                 sh2[ch] = (float)((double)b2[ch] + inv * ((double)fc1_b[ch] - (double)rm2[ch]));
         }
