@@ -107,9 +107,9 @@ __global__ __launch_bounds__(256) void mid2b_kernel(
 }
 
 
-// Fused mid1+mid2a+mid2b for n <= 72: one 256-thread block per unit with V1, A2, EQ, C and M
+// Fused mid1+mid2a+mid2b for n <= 72: one 1024-thread block per unit with V1, A2, EQ, C and M
 // staged in LDS, so every inner loop reads LDS instead of chasing dependent global loads.
-__global__ __launch_bounds__(256) void mid_fused_kernel(
+__global__ __launch_bounds__(1024) void mid_fused_kernel(
     const float* __restrict__ EQp, const float* __restrict__ Sep, const float* __restrict__ A2,
     const float* __restrict__ sh2, const float* __restrict__ sig2, const float* __restrict__ fc1_w,
     const float* __restrict__ fc2_w, const float* __restrict__ g2, const double* __restrict__ qbar,
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void mid_fused_kernel(
     float* cfs = md2s + FC_H;                // [100]  md2h / sig2
     float* md2hs = cfs + FC_H;               // [100]
     const int u = blockIdx.x, tid = threadIdx.x;
-    for (int e = tid; e < FC_H * n; e += 256) {
+    for (int e = tid; e < FC_H * n; e += 1024) {
         const int r = e / n, w = e % n;
         const size_t ch = (size_t)u * FC_H + r;
         V1s[r * ld + w] = fc1_w[ch * n + w];
@@ -139,9 +139,9 @@ __global__ __launch_bounds__(256) void mid_fused_kernel(
         for (int c = 0; c < ACH; ++c) eq += (double)EQp[(((size_t)u * ACH + c) * FC_H + r) * NS + w];
         EQl[r * ld + w] = (float)eq;
     }
-    for (int e = tid; e < n * n; e += 256) Cs[e] = C[(size_t)u * NS * NS + (size_t)(e / n) * NS + (e % n)];
-    for (int w = tid; w < n; w += 256) qb[w] = (float)qbar[(size_t)u * NS + w];
-    for (int r = tid; r < FC_H; r += 256) {
+    for (int e = tid; e < n * n; e += 1024) Cs[e] = C[(size_t)u * NS * NS + (size_t)(e / n) * NS + (e % n)];
+    for (int w = tid; w < n; w += 1024) qb[w] = (float)qbar[(size_t)u * NS + w];
+    for (int r = tid; r < FC_H; r += 1024) {
         double s = 0;
         for (int c = 0; c < ACH; ++c) s += (double)Sep[((size_t)u * ACH + c) * FC_H + r];
         se[r] = (float)s;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void mid_fused_kernel(
         cfs[r] = (float)((dg2 / (double)B) / sg);
     }
     __syncthreads();
-    for (int e = tid; e < NS * NS; e += 256) {
+    for (int e = tid; e < NS * NS; e += 1024) {
         const int v = e / NS, w = e % NS;
         float acc = 0.f;
         if (v < n && w < n) {
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void mid_fused_kernel(
         }
         M[(size_t)u * NS * NS + e] = acc;
     }
-    for (int e = tid; e < FC_H * NS; e += 256) {
+    for (int e = tid; e < FC_H * NS; e += 1024) {
         const int r = e / NS, w = e % NS;
         const size_t ch = (size_t)u * FC_H + r;
         const double sv = sc * (double)fc2_w[ch];
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void mid_fused_kernel(
         Tt[ch * NS + w] = tv;
     }
     __syncthreads();
-    for (int w = tid; w < NS; w += 256) {
+    for (int w = tid; w < NS; w += 1024) {
         double k0 = 0;
         if (w < n) {
             for (int r = 0; r < FC_H; ++r) k0 = fma((double)A2s[r * ld + w], (double)md2s[r], k0);
@@ -218,7 +218,7 @@ static size_t mid_fused_lds(int n) {
 int launch_mid_bwd(explainn_ctx* c, const explainn_params* p, const explainn_grads* g, int B,
                    hipStream_t s) {
     if (c->n <= 72) {
-        hipLaunchKernelGGL(mid_fused_kernel, dim3(c->U), dim3(256), mid_fused_lds(c->n), s, c->EQp,
+        hipLaunchKernelGGL(mid_fused_kernel, dim3(c->U), dim3(1024), mid_fused_lds(c->n), s, c->EQp,
                            c->Sep, c->A2, c->sh2, c->sig2, p->fc1_w, p->fc2_w, p->bn2_w, c->qbar,
                            c->C, c->Tt, c->M, c->k0p, g->fc2_w, g->bn2_w, g->bn2_b, g->fc1_b,
                            g->fc1_w, c->n, c->NS, B, c->ACH, c->fwd_scale);

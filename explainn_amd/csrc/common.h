@@ -52,6 +52,7 @@ struct explainn_ctx {
     double* qbar;         // [U][NS]
     float* C;             // [U][NS][NS]      centred covariance of q over the batch
     float* A2;            // [U][100][NS]     FC1 weights with BN2 folded in
+    float* A2f;           // [U][4][NKS][64]  the same in MFMA A-fragment order (fc_fwd stages it)
     int NX;
     float* sh2;           // [U][100]
     float* sig2;          // [U][100]
@@ -118,7 +119,8 @@ int fc_configure(explainn_ctx* c);
 
 // q = exp(alpha*ext + shift): every consumer must evaluate it identically
 __device__ __forceinline__ float qval(float alpha, float ext, float shift) {
-    return expf(fmaf(alpha, ext, shift));
+    // v_exp_f32 path: ~2 ulp, far inside the 1e-4 parity budget, and 10x fewer instructions
+    return __expf(fmaf(alpha, ext, shift));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

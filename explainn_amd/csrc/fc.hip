@@ -36,7 +36,7 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
 template <int NQ, int MODE>
 __global__ __launch_bounds__(256) void fc_fwd_kernel(
     const float* __restrict__ ext, const float* __restrict__ alpha,
-    const float* __restrict__ shift, const float* __restrict__ A2, const float* __restrict__ sh2,
+    const float* __restrict__ shift, const float* __restrict__ A2f, const float* __restrict__ sh2,
     const float* __restrict__ V2, uint4* __restrict__ bits, float* __restrict__ zout,
     const uint8_t* __restrict__ keep_mask, uint32_t thresh16, float scale, uint32_t seed_lo,
     uint32_t seed_hi, const float* __restrict__ c2, const float* __restrict__ g3,
@@ -49,11 +49,11 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(
     __shared__ __attribute__((aligned(16))) float v2s[128];
     const int u = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rc = lane & 31, kk = lane >> 5;
-    // stage the A fragments: Af[(t*NKS+s)*64 + l] = A2[32t + (l&31)][2s + (l>>5)]
-    for (int i = tid; i < FC_RT * NKS * 64; i += 256) {
-        const int l = i & 63, s = (i >> 6) % NKS, t = (i >> 6) / NKS;
-        const int r = 32 * t + (l & 31), w = 2 * s + (l >> 5);
-        Af[i] = (r < FC_H && w < n) ? A2[((size_t)u * FC_H + r) * NS + w] : 0.f;
+    // stage the A fragments (prep2 wrote them in fragment order):
+    // Af[(t*NKS+s)*64 + l] = A2[32t + (l&31)][2s + (l>>5)]
+    {
+        const float* src = A2f + (size_t)u * FC_RT * NKS * 64;
+        for (int i = tid; i < FC_RT * NKS * 64; i += 256) Af[i] = src[i];
     }
     if (tid < 128) {
         sh2s[tid] = tid < FC_H ? sh2[(size_t)u * FC_H + tid] : 0.f;
@@ -143,7 +143,7 @@ int launch_fc_fwd(explainn_ctx* c, const explainn_params* p, int B, bool train,
         thresh = (uint32_t)(drop_p * 65536.0 + 0.5);
     }
     if (train) { c->fwd_drop = mode > 1; c->fwd_scale = scale; }
-#define ARGS c->ext, c->alpha, c->shift, c->A2, c->sh2, p->fc2_w, c->bits, c->z, keep_mask, thresh, \
+#define ARGS c->ext, c->alpha, c->shift, c->A2f, c->sh2, p->fc2_w, c->bits, c->z, keep_mask, thresh, \
              scale, (uint32_t)seed, (uint32_t)(seed >> 32), p->fc2_b, p->bn3_w, p->bn3_b,          \
              p->bn3_rm, p->bn3_rv, c->o, c->n, c->Bs, B, c->U
 #define CALL(N)                                                                                    \
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64) void passA_kernel(const float* __restrict__ qbw
         for (int t = 0; t < FC_RT; ++t)
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[t][g] = 0.f;
-#pragma unroll 2
+#pragma unroll 8
         for (int b0 = bbeg; b0 < bend; b0 += 2) {
             const int b = b0 + kk;
             const bool live = b < bend;

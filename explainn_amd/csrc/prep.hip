@@ -188,85 +188,86 @@ static size_t prep2_lds(int n, int NS) {
 }
 
 template <bool TRAIN>
-__global__ __launch_bounds__(256) void prep2_kernel(
+__global__ __launch_bounds__(1024) void prep2_kernel(
     const float* __restrict__ fc1_w, const float* __restrict__ fc1_b,
     const float* __restrict__ g2, const float* __restrict__ b2, float* __restrict__ rm2,
     float* __restrict__ rv2, int64_t* nbt, const float* __restrict__ qs0,
     const float* __restrict__ S1p, const float* __restrict__ S2p, double* __restrict__ qbar,
-    float* __restrict__ C, float* __restrict__ A2, float* __restrict__ sh2,
-    float* __restrict__ sig2, int n, int NS, int B, int QCH) {
+    float* __restrict__ C, float* __restrict__ A2, float* __restrict__ A2f,
+    float* __restrict__ sh2, float* __restrict__ sig2, int n, int NS, int NKS, int B, int QCH) {
     extern __shared__ double sm[];            // qb[NS] (double) | Cs[n][n] | V1s[100][n+1]
     const int u = blockIdx.x, tid = threadIdx.x;
+    constexpr int NT = 1024;
     if (!TRAIN) {
-        for (int e = tid; e < FC_H * NS; e += 256) {
+        for (int e = tid; e < FC_H * NS; e += NT) {
             const int r = e / NS, w = e % NS, ch = u * FC_H + r;
             const double inv = (double)g2[ch] / sqrt((double)rv2[ch] + BN_EPS_D);
-            const float a = (w < n) ? (float)(inv * (double)fc1_w[(size_t)ch * n + w]) : 0.f;
-            A2[(size_t)ch * NS + w] = a;
+            A2[(size_t)ch * NS + w] = (w < n) ? (float)(inv * (double)fc1_w[(size_t)ch * n + w]) : 0.f;
             if (w == 0)
                 sh2[ch] = (float)((double)b2[ch] + inv * ((double)fc1_b[ch] - (double)rm2[ch]));
         }
-        return;
-    }
-    double* qb = sm;
-    float* Cs = (float*)(sm + NS);
-    float* V1s = Cs + n * n;
-    const int ld = n + 1;
-    const double invB = 1.0 / (double)B;
-    for (int e = tid; e < FC_H * n; e += 256)
-        V1s[(e / n) * ld + (e % n)] = fc1_w[(size_t)u * FC_H * n + e];
-    // combine the chunk partials (fixed order -> deterministic)
-    for (int w = tid; w < n; w += 256) {
-        double s1 = 0;
-        for (int c = 0; c < QCH; ++c) s1 += (double)S1p[((size_t)u * QCH + c) * NS + w];
-        qb[w] = s1 * invB;                    // mean of (q - s); the shift is added below
-    }
-    __syncthreads();
-    for (int e = tid; e < n * n; e += 256) {
-        const int w = e / n, wp = e % n;
-        double s2 = 0;
-        for (int c = 0; c < QCH; ++c) s2 += (double)S2p[(((size_t)u * QCH + c) * NS + w) * NS + wp];
-        // sum (q_w - s_w)(q_w' - s_w') = S2r - s_w * S1[w']
-        const double sw = (double)qs0[(size_t)u * NS + w];
-        const double cov = (s2 * invB - sw * qb[wp]) - qb[w] * qb[wp];
-        Cs[e] = (float)cov;
-        C[(size_t)u * NS * NS + (size_t)w * NS + wp] = (float)cov;
-    }
-    __syncthreads();
-    for (int w = tid; w < n; w += 256) {
-        const double v = qb[w] + (double)qs0[(size_t)u * NS + w];
-        qbar[(size_t)u * NS + w] = v;
-        qb[w] = v;                            // from here on qb = mean of q
-    }
-    __syncthreads();
-    const int r = tid >> 1, half = tid & 1;
-    const int rr = r < FC_H ? r : FC_H - 1;
-    const float* v1 = V1s + rr * ld;
-    double var = 0;
-    for (int wp = half; wp < n; wp += 2) {
-        double t = 0;
-        for (int w = 0; w < n; ++w) t = fma((double)v1[w], (double)Cs[w * n + wp], t);
-        var = fma(t, (double)v1[wp], var);
-    }
-    var += __shfl_xor(var, 1, 64);
-    if (r < FC_H) {
-        const int ch = u * FC_H + r;
+    } else {
+        double* qb = sm;
+        float* Cs = (float*)(sm + NS);
+        float* V1s = Cs + n * n;
+        const int ld = n + 1;
+        const double invB = 1.0 / (double)B;
+        for (int e = tid; e < FC_H * n; e += NT)
+            V1s[(e / n) * ld + (e % n)] = fc1_w[(size_t)u * FC_H * n + e];
+        // combine the chunk partials (fixed order -> deterministic)
+        for (int w = tid; w < n; w += NT) {
+            double s1 = 0;
+            for (int c = 0; c < QCH; ++c) s1 += (double)S1p[((size_t)u * QCH + c) * NS + w];
+            qb[w] = s1 * invB;                // mean of (q - s); the shift is added below
+        }
+        __syncthreads();
+        for (int e = tid; e < n * n; e += NT) {
+            const int w = e / n, wp = e % n;
+            double s2 = 0;
+            for (int c = 0; c < QCH; ++c)
+                s2 += (double)S2p[(((size_t)u * QCH + c) * NS + w) * NS + wp];
+            // sum (q_w - s_w)(q_w' - s_w') = S2r - s_w * S1[w']
+            const double sw = (double)qs0[(size_t)u * NS + w];
+            const double cov = (s2 * invB - sw * qb[wp]) - qb[w] * qb[wp];
+            Cs[e] = (float)cov;
+            C[(size_t)u * NS * NS + (size_t)w * NS + wp] = (float)cov;
+        }
+        __syncthreads();
+        for (int w = tid; w < n; w += NT) {
+            const double v = qb[w] + (double)qs0[(size_t)u * NS + w];
+            qbar[(size_t)u * NS + w] = v;
+            qb[w] = v;                        // from here on qb = mean of q
+        }
+        __syncthreads();
+        // eight threads per hidden channel: each takes every 8th column w' of the quadratic form
+        const int r = tid >> 3, part = tid & 7;
+        const int rr = r < FC_H ? r : FC_H - 1;
+        const float* v1 = V1s + rr * ld;
+        double var = 0;
+        for (int wp = part; wp < n; wp += 8) {
+            double t = 0;
+            for (int w = 0; w < n; ++w) t = fma((double)v1[w], (double)Cs[w * n + wp], t);
+            var = fma(t, (double)v1[wp], var);
+        }
+        var += __shfl_xor(var, 1, 64); var += __shfl_xor(var, 2, 64); var += __shfl_xor(var, 4, 64);
+        const int ch = u * FC_H + rr;
         var = var > 0 ? var : 0;
         const double sg = sqrt(var + BN_EPS_D);
         const double inv = (double)g2[ch] / sg;
         double shp = 0, meanp = 0;
-        for (int w = half; w < NS; w += 2) {
+        for (int w = part; w < NS; w += 8) {
             float a = 0.f;
             if (w < n) {
                 a = (float)(inv * (double)v1[w]);
                 shp = fma((double)a, qb[w], shp);
                 meanp = fma((double)v1[w], qb[w], meanp);
             }
-            A2[(size_t)ch * NS + w] = a;
+            if (r < FC_H) A2[(size_t)ch * NS + w] = a;
         }
-        shp += __shfl_xor(shp, 1, 64);
-        meanp += __shfl_xor(meanp, 1, 64);
-        if (half == 0) {
+        shp += __shfl_xor(shp, 1, 64); shp += __shfl_xor(shp, 2, 64); shp += __shfl_xor(shp, 4, 64);
+        meanp += __shfl_xor(meanp, 1, 64); meanp += __shfl_xor(meanp, 2, 64);
+        meanp += __shfl_xor(meanp, 4, 64);
+        if (r < FC_H && part == 0) {
             const double mean = (double)fc1_b[ch] + meanp;
             sh2[ch] = (float)((double)b2[ch] - shp);
             sig2[ch] = (float)sg;
@@ -274,25 +275,30 @@ __global__ __launch_bounds__(256) void prep2_kernel(
             rv2[ch] = (float)((1 - BN_MOM_D) * (double)rv2[ch] +
                               BN_MOM_D * var * (double)B / (double)(B - 1));
         }
-    } else {
-        double d0 = 0;
-        d0 += __shfl_xor(d0, 1, 64);          // keep the shuffles convergent for the idle lanes
-        d0 += __shfl_xor(d0, 1, 64);
+        if (u == 0 && tid == 0 && nbt) *nbt += 1;
     }
-    if (u == 0 && tid == 0 && nbt) *nbt += 1;
+    // the same weights in MFMA A-fragment order for fc_fwd:
+    // A2f[((t*NKS + s)*64) + l] = A2[32t + (l&31)][2s + (l>>5)]
+    __syncthreads();
+    for (int i = tid; i < 4 * NKS * 64; i += NT) {
+        const int l = i & 63, s = (i >> 6) % NKS, t = (i >> 6) / NKS;
+        const int r = 32 * t + (l & 31), w = 2 * s + (l >> 5);
+        A2f[(size_t)u * 4 * NKS * 64 + i] =
+            (r < FC_H && w < n) ? A2[((size_t)u * FC_H + r) * NS + w] : 0.f;
+    }
 }
 
 int launch_prep2(explainn_ctx* c, const explainn_params* p, int B, bool train, hipStream_t s) {
     if (train)
-        hipLaunchKernelGGL(prep2_kernel<true>, dim3(c->U), dim3(256), prep2_lds(c->n, c->NS), s,
+        hipLaunchKernelGGL(prep2_kernel<true>, dim3(c->U), dim3(1024), prep2_lds(c->n, c->NS), s,
                            p->fc1_w, p->fc1_b, p->bn2_w, p->bn2_b, p->bn2_rm, p->bn2_rv, p->bn2_nbt,
-                           c->qs0, c->qS1p, c->qS2p, c->qbar, c->C, c->A2, c->sh2, c->sig2, c->n,
-                           c->NS, B, c->QCH);
+                           c->qs0, c->qS1p, c->qS2p, c->qbar, c->C, c->A2, c->A2f, c->sh2, c->sig2,
+                           c->n, c->NS, (c->NQ + 1) / 2, B, c->QCH);
     else
-        hipLaunchKernelGGL(prep2_kernel<false>, dim3(c->U), dim3(256), 0, s, p->fc1_w, p->fc1_b,
+        hipLaunchKernelGGL(prep2_kernel<false>, dim3(c->U), dim3(1024), 0, s, p->fc1_w, p->fc1_b,
                            p->bn2_w, p->bn2_b, p->bn2_rm, p->bn2_rv, (int64_t*)nullptr, c->qs0,
-                           c->qS1p, c->qS2p, c->qbar, c->C, c->A2, c->sh2, c->sig2, c->n, c->NS, B,
-                           c->QCH);
+                           c->qS1p, c->qS2p, c->qbar, c->C, c->A2, c->A2f, c->sh2, c->sig2, c->n,
+                           c->NS, (c->NQ + 1) / 2, B, c->QCH);
     LAUNCH_CHECK();
     return EXPLAINN_OK;
 }

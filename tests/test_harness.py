@@ -1,0 +1,119 @@
+"""Host-side harness (Trainer, _train helpers, predict, sequence): CPU logic tests plus GPU runs
+checked against the reference `Trainer` golden run (tests/golden/trainer_run.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+
+def test_sequence_matches_reference_vectors():
+    from explainn_amd import sequence as s
+    z = np.load(GOLDEN + "/encoding.npz", allow_pickle=False)
+    for i in range(5):
+        q = str(z["seq%d" % i]); e = s.one_hot_encode(q)
+        assert e.dtype == np.float64 and np.array_equal(e, z["enc%d" % i])
+        assert np.array_equal(s.rc_one_hot_encoding(e), z["rc%d" % i])
+    assert s.rc("AACGTN") == "NACGTT"
+    assert s.one_hot_decode(s.one_hot_encode("ACNGT")) == "ACNGT"
+    many = s.one_hot_encode_many(["ACGT", "TTNN"])
+    assert many.shape == (2, 4, 4) and np.array_equal(s.rc_one_hot_encoding_many(many)[0],
+                                                      many[0][::-1, ::-1])
+
+
+def test_loader_avoids_single_sample_last_batch():
+    from explainn_amd.train import _avoid_single_sample_batch, _get_data_loader
+    assert _avoid_single_sample_batch(101, 100) == 99          # 101 % 100 == 1 -> shrink
+    assert _avoid_single_sample_batch(100, 100) == 100
+    assert _avoid_single_sample_batch(7, 3) == 1               # 7%3==1 -> 2, 7%2==1 -> 1
+    dl = _get_data_loader(np.zeros((101, 4, 30)), np.zeros((101, 1)), 100)
+    assert all(b[0].shape[0] > 1 for b in dl)
+
+
+def test_tsv_reader_and_rc_augmentation(tmp_path):
+    from explainn_amd.train import _get_seqs_labels_ids
+    p = tmp_path / "d.tsv"
+    p.write_text("a\tACGTAC\t1\t0.5\nb\tNNGTAC\t0\t1.5\n")
+    seqs, labels, ids = _get_seqs_labels_ids(str(p), reverse_complement=True)
+    assert seqs.shape == (4, 4, 6) and labels.shape == (4, 2) and list(ids) == ["a", "b", "a", "b"]
+    assert np.array_equal(seqs[2], seqs[0][::-1, ::-1]) and seqs[1][:, 0].sum() == 0
+
+
+def _trainer_fixture():
+    z = np.load(os.path.join(GOLDEN, "trainer_run.npz"), allow_pickle=False)
+    U, k, L, T, B, N = [int(v) for v in z["cfg"]]
+    codes = z["codes"]
+    x = np.zeros((codes.shape[0], 4, L), dtype=np.float32)
+    for a in range(4):
+        x[:, a, :] = codes == a
+    sd = {key[3:]: torch.from_numpy(np.array(z[key])) for key in z.files if key.startswith("sd/")}
+    return z, (U, k, L, T, B, N), torch.from_numpy(x), torch.from_numpy(z["y"]), sd
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [True, False])
+def test_trainer_run_matches_reference(tmp_path, fused):
+    """3 epochs of Trainer.train_and_validate on the reference's data/initialisation: the values
+    written to train.txt / validation.txt and the checkpoint bookkeeping match the reference run
+    (dropout off; tolerance 1e-4 on losses, 5e-3 on rank metrics of 32 validation points)."""
+    from torch.utils.data import DataLoader, TensorDataset
+    from explainn_amd import ExplaiNN, get_loss, get_metrics, get_optimizer
+    from explainn_amd.selene import Trainer, _load_checkpoint_file
+    z, (U, k, L, T, B, N), x, y, sd = _trainer_fixture()
+    model = ExplaiNN(U, k, L, T)
+    model.load_state_dict(sd)
+    model.dropout_p = 0.0
+    loaders = {"train": DataLoader(TensorDataset(x[:N], y[:N]), B, shuffle=False),
+               "validation": DataLoader(TensorDataset(x[N:], y[N:]), B, shuffle=False)}
+    crit = get_loss("binary")
+    if not fused:
+        crit = torch.nn.BCEWithLogitsLoss(reduction="mean", pos_weight=torch.ones(1))  # autograd path
+    spe = N // B
+    tr = Trainer(model, loaders, crit, get_metrics("binary"),
+                 get_optimizer(model.parameters(), 0.003), max_steps=spe * 3, patience=spe * 10,
+                 report_stats_every_n_steps=spe, output_dir=str(tmp_path), cpu_n_threads=1,
+                 use_cuda=True, logging_verbosity=0)
+    assert tr._fused_step_available() == fused
+    tr.train_and_validate()
+    train_txt = open(tmp_path / "train.txt").read().split()
+    assert train_txt[0] == "loss"
+    got = np.array([float(v) for v in train_txt[1:]])
+    assert np.abs(got - z["train_txt"]).max() < 1e-4, (got, z["train_txt"])
+    lines = open(tmp_path / "validation.txt").read().strip().split("\n")
+    assert lines[0] == str(z["val_header"])
+    val = np.array([[float(v) for v in ln.split("\t")] for ln in lines[1:]])
+    assert np.abs(val[:, 0] - z["val_txt"][:, 0]).max() < 1e-4
+    assert np.abs(val[:, 1:] - z["val_txt"][:, 1:]).max() < 5e-3
+    ck = _load_checkpoint_file(str(tmp_path / "best_model.pth.tar"))
+    assert sorted(ck.keys()) == list(z["ck_keys"]) and ck["arch"] == str(z["ck_arch"])
+    assert ck["step"] == int(z["ck_step"]) and abs(ck["min_loss"] - float(z["ck_min_loss"])) < 1e-4
+    assert np.abs(ck["state_dict"]["linears.0.weight"].numpy() - z["ck_filters"]).max() < 1e-4
+
+
+@pytest.mark.gpu
+def test_train_entry_point_and_predict_roundtrip(tmp_path):
+    """`_train` (train.py:304) end to end on a toy problem, then `_load_model` + `predict` on the
+    checkpoint it wrote: [Fwd, Rev, Mean, Max] consistent with direct eval-mode calls."""
+    from torch.utils.data import DataLoader, TensorDataset
+    from explainn_amd.predict import _load_model, predict
+    from explainn_amd.train import _train
+    z, (U, k, L, T, B, N), x, y, sd = _trainer_fixture()
+    loaders = {"train": DataLoader(TensorDataset(x[:N], y[:N]), B, shuffle=True),
+               "validation": DataLoader(TensorDataset(x[N:], y[N:]), B)}
+    torch.manual_seed(0)
+    _train(L, T, loaders, "binary", N // B, cnn_units=U, kernel_size=k, max_epochs=2, patience=5,
+           output_dir=str(tmp_path))
+    for name in ("train.txt", "validation.txt", "best_model.pth.tar", "selene.log"):
+        assert (tmp_path / name).exists(), name
+    model = _load_model(str(tmp_path / "best_model.pth.tar"))
+    assert not model.training and model._options["cnn_units"] == U
+    preds = predict(model, x[:10].numpy(), batch_size=4)
+    assert preds.shape == (10, T, 4) and preds.dtype == np.float64
+    with torch.no_grad():
+        fwd = model(x[:10].cuda()).cpu().numpy()
+        rev = model(torch.flip(x[:10], dims=(1, 2)).cuda()).cpu().numpy()
+    assert np.abs(preds[:, :, 0] - fwd).max() < 1e-6 and np.abs(preds[:, :, 1] - rev).max() < 1e-6
+    assert np.allclose(preds[:, :, 2], (fwd + rev) / 2, atol=1e-6)
+    assert np.allclose(preds[:, :, 3], np.maximum(fwd, rev), atol=1e-6)

@@ -184,6 +184,56 @@ def make_case(name, U, k, L, T, B, seed, n_frac=0.0, negative_gamma=False, loss_
     print("%-28s %8.1f KB" % (name, os.path.getsize(path) / 1024))
 
 
+def make_trainer_case():
+    """A short reference `Trainer.train_and_validate()` run (selene/__init__.py:248-271) on a tiny
+    synthetic data set: dropout off, loaders unshuffled -> deterministic; the values it logs to
+    train.txt / validation.txt and the checkpoint's bookkeeping are the expected outputs."""
+    import tempfile
+    from torch.utils.data import DataLoader, TensorDataset
+    from architectures import get_metrics
+    from selene import Trainer
+    U, k, L, T, B, N = 6, 11, 60, 1, 16, 64
+    torch.manual_seed(21)
+    model = ExplaiNN(U, k, L, T)
+    model.linears[9].p = 0.0
+    codes = make_codes(N + 32, L, 22, 0.01)
+    g = torch.Generator().manual_seed(23)
+    # labels correlated with the presence of a motif so the metrics are meaningful
+    motif = np.array([0, 1, 2, 3, 0, 1], dtype=np.uint8)
+    y = np.zeros((N + 32, T), dtype=np.float32)
+    for i in range(N + 32):
+        if torch.rand(1, generator=g).item() < 0.5:
+            pos = int(torch.randint(0, L - len(motif), (1,), generator=g).item())
+            codes[i, pos:pos + len(motif)] = motif
+            y[i, 0] = 1.0
+    x = torch.from_numpy(codes_to_onehot(codes)); yt = torch.from_numpy(y)
+    loaders = {"train": DataLoader(TensorDataset(x[:N], yt[:N]), B, shuffle=False),
+               "validation": DataLoader(TensorDataset(x[N:], yt[N:]), B, shuffle=False)}
+    out = dict(cfg=np.array([U, k, L, T, B, N], dtype=np.int64), codes=codes, y=y)
+    out.update(sd_np(model, "sd/"))
+    steps_per_epoch = N // B
+    with tempfile.TemporaryDirectory() as d:
+        tr = Trainer(model, loaders, get_loss("binary"), get_metrics("binary"),
+                     get_optimizer(model.parameters(), 0.003), max_steps=steps_per_epoch * 3,
+                     patience=steps_per_epoch * 10, report_stats_every_n_steps=steps_per_epoch,
+                     output_dir=d, cpu_n_threads=1, use_cuda=False, logging_verbosity=0)
+        tr.train_and_validate()
+        train_txt = open(os.path.join(d, "train.txt")).read().split()
+        val_lines = open(os.path.join(d, "validation.txt")).read().strip().split("\n")
+        # written seconds ago by this very process (min_loss is a numpy scalar, which the
+        # weights_only unpickler rejects); not a file that ships with the reference
+        ck = torch.load(os.path.join(d, "best_model.pth.tar"), weights_only=False)
+    out["train_txt"] = np.array([float(v) for v in train_txt[1:]])
+    out["val_header"] = np.array(val_lines[0])
+    out["val_txt"] = np.array([[float(v) for v in ln.split("\t")] for ln in val_lines[1:]])
+    out["ck_step"] = np.array(ck["step"]); out["ck_min_loss"] = np.array(ck["min_loss"])
+    out["ck_arch"] = np.array(ck["arch"])
+    out["ck_keys"] = np.array(sorted(ck.keys()))
+    out["ck_filters"] = ck["state_dict"]["linears.0.weight"].numpy()
+    np.savez_compressed(os.path.join(OUT, "trainer_run.npz"), **out)
+    print("trainer_run", out["train_txt"], out["val_txt"])
+
+
 def make_encoding_case():
     seqs = ["ACGT", "acgtn", "NNACGTRYACGT", "TTTTGGGGCCCCAAAA", "A"]
     out = {}
@@ -199,6 +249,9 @@ def make_encoding_case():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     make_encoding_case()
+    if len(sys.argv) > 1 and sys.argv[1] == "trainer":
+        make_trainer_case()
+        sys.exit(0)
     #          name               U   k   L   T   B  seed
     make_case("tiny_u1_k5",       1,  5,  26, 1,  2, 10)
     make_case("tiny_u3_k5_N",     3,  5,  26, 3, 16, 11, n_frac=0.1, negative_gamma=True)
