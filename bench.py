@@ -52,6 +52,9 @@ def cpu_baseline(budget_s=20.0):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    # a 1-GPU box gives this job a 16-core share of the host (more threads only oversubscribe:
+    # 256 threads measured 72 seq/s against 16 threads' several hundred)
+    cores = min(cores, int(os.environ.get("EXPLAINN_CPU_THREADS", "16")))
     torch.set_num_threads(cores)
     sd = torch_ref.init_state(U, K, L, T, seed=0)
     x, y = synthetic_batch(B_PER_GPU, 1, "cpu")
