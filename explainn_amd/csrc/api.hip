@@ -44,6 +44,7 @@ void carve(explainn_ctx* c, Carver& cv) {
     cv.take(&c->sig1, U4);
     cv.take(&c->Gw, U4 * K4);
     cv.take(&c->Wt, (int64_t)c->Uq * c->k * 20);
+    cv.take(&c->lut, (int64_t)(c->U4 / 2) * ((c->k + 1) / 2) * 32);
     cv.take(&c->ext, U4 * n * Bs);
     cv.take(&c->idx, U4 * n * Bs);
     cv.take(&c->qbw, (U * Bs + 2) * NS);
@@ -168,6 +169,7 @@ extern "C" int explainn_create(explainn_ctx** out, int cnn_units, int kernel_siz
     int rc = prep_configure(c);
     if (rc == EXPLAINN_OK) rc = bwd_configure(c);
     if (rc == EXPLAINN_OK) rc = fc_configure(c);
+    if (rc == EXPLAINN_OK) rc = conv_configure(c);
     if (rc != EXPLAINN_OK) { hipFree(c->base); delete c; return rc; }
     *out = c;
     return EXPLAINN_OK;

@@ -264,33 +264,47 @@ __global__ __launch_bounds__(64) void conv_bwd_kernel(const float* __restrict__ 
         if (u >= U) break;
 #pragma unroll
         for (int i = 0; i < 4 * K; ++i) mine[i] = 0.f;
-        for (int w = 0; w < n; ++w) {
-            const size_t off = ((size_t)u * n + w) * Bs + b;
-            const float dyv = dy[off];
-            const int ps = POOLW * w + (int)idx[off];
-            const int w0 = ps >> 4, sh = (ps & 15) * 2;
-            const uint32_t c0 = pks[w0 * 64 + lane], c1 = pks[(w0 + 1) * 64 + lane],
-                           c2 = pks[(w0 + 2) * 64 + lane];
-            const uint32_t lo = __funnelshift_r(c0, c1, sh), hi = __funnelshift_r(c1, c2, sh);
-            const int n0 = ps >> 5, nsh = ps & 31;
-            const uint32_t nm = __funnelshift_r(nms[n0 * 64 + lane], nms[(n0 + 1) * 64 + lane], nsh) & KMASK;
-            // private row: plain read-modify-write (LDS float atomics serialise per lane on
-            // gfx950).  All K reads are issued before the K writes so they pipeline; taps of one
-            // window touch distinct rows j, and the LDS queue keeps windows in order.
-            int slot[K];
-            float cur[K];
+        // dy / idx for four windows are requested together: one global-load latency per four
+        // windows instead of one per window (the LDS read-modify-write chain cannot hide it)
+        for (int wb = 0; wb < n; wb += 4) {
+            float dyq[4];
+            int psq[4];
 #pragma unroll
-            for (int j = 0; j < K; ++j) {
-                const uint32_t code = (j < 16 ? (lo >> (2 * j)) : (hi >> (2 * (j - 16)))) & 3u;
-                slot[j] = j * 4 + (int)code;
-                cur[j] = mine[slot[j]];
+            for (int q = 0; q < 4; ++q) {
+                const int w = min(wb + q, n - 1);
+                const size_t off = ((size_t)u * n + w) * Bs + b;
+                dyq[q] = (wb + q < n) ? dy[off] : 0.f;
+                psq[q] = POOLW * w + (int)idx[off];
             }
-            if (__any(nm != 0u)) {
 #pragma unroll
-                for (int j = 0; j < K; ++j) mine[slot[j]] = cur[j] + (((nm >> j) & 1u) ? 0.f : dyv);
-            } else {
+            for (int q = 0; q < 4; ++q) {
+                if (wb + q >= n) break;                    // uniform
+                const float dyv = dyq[q];
+                const int ps = psq[q];
+                const int w0 = ps >> 4, sh = (ps & 15) * 2;
+                const uint32_t c0 = pks[w0 * 64 + lane], c1 = pks[(w0 + 1) * 64 + lane],
+                               c2 = pks[(w0 + 2) * 64 + lane];
+                const uint32_t lo = __funnelshift_r(c0, c1, sh), hi = __funnelshift_r(c1, c2, sh);
+                const int n0 = ps >> 5, nsh = ps & 31;
+                const uint32_t nm = __funnelshift_r(nms[n0 * 64 + lane], nms[(n0 + 1) * 64 + lane], nsh) & KMASK;
+                // private row: plain read-modify-write (LDS float atomics serialise per lane on
+                // gfx950).  All K reads are issued before the K writes so they pipeline; taps of
+                // one window touch distinct rows j, and the LDS queue keeps windows in order.
+                int slot[K];
+                float cur[K];
 #pragma unroll
-                for (int j = 0; j < K; ++j) mine[slot[j]] = cur[j] + dyv;
+                for (int j = 0; j < K; ++j) {
+                    const uint32_t code = (j < 16 ? (lo >> (2 * j)) : (hi >> (2 * (j - 16)))) & 3u;
+                    slot[j] = j * 4 + (int)code;
+                    cur[j] = mine[slot[j]];
+                }
+                if (__any(nm != 0u)) {
+#pragma unroll
+                    for (int j = 0; j < K; ++j) mine[slot[j]] = cur[j] + (((nm >> j) & 1u) ? 0.f : dyv);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < K; ++j) mine[slot[j]] = cur[j] + dyv;
+                }
             }
         }
         __syncthreads();

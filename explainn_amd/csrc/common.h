@@ -43,6 +43,7 @@ struct explainn_ctx {
     double* sig1;         // [U4]
     double* Gw;           // [U4][4k]
     float* Wt;            // [Uq][k][5][4]    filter taps, unit-quad interleaved, code 4 -> 0
+    float* lut;           // [U4/2][ceil(k/2)][16] float2: dinucleotide tables per unit pair
     float* ext;           // [U4][n][Bs]      pooled extreme of the raw gather sum
     uint8_t* idx;         // [U4][n][Bs]      argmax offset 0..6 inside the pooling window
     float* qbw;           // [U][Bs][NS]      q = exp(alpha*ext+shift), sequence-major
@@ -116,6 +117,7 @@ int launch_fin_bwd(explainn_ctx* c, const explainn_params* p, const explainn_gra
 int prep_configure(explainn_ctx* c);
 int bwd_configure(explainn_ctx* c);
 int fc_configure(explainn_ctx* c);
+int conv_configure(explainn_ctx* c);
 
 // q = exp(alpha*ext + shift): every consumer must evaluate it identically
 __device__ __forceinline__ float qval(float alpha, float ext, float shift) {

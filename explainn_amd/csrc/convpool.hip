@@ -1,68 +1,151 @@
 // The filter bank: Conv1d(4U->U, k, groups=U) + BatchNorm1 + exp + MaxPool1d(7,7)
 // (architectures/__init__.py:73-81) as ONE gather kernel that never materialises the conv output.
 //
-// One-hot input makes the convolution a gather: conv[b,u,p] = sum_j W[u, s[b,p+j], j].  A lane owns
-// one sequence and four units: the taps of a unit quad sit in LDS as W[j][code] -> float4 (code 4 =
-// N = zeros), so one ds_read_b128 at byte offset (j*80 + code*16) feeds four accumulators; lanes
-// that share a code hit the same address (broadcast) and the five codes of a tap occupy twenty
-// consecutive banks, so the reads are conflict-free by construction.
+// One-hot input makes the convolution a gather: conv[b,u,p] = sum_j W[u, s[b,p+j], j].
+// Dinucleotide tables halve the gather: for each pair of taps t, LUT[t][c0 c1] holds the sum of
+// the two taps for that 2-mer, so a 19-tap window is 10 LDS reads + 10 adds instead of 19 + 19.
+// The table size is chosen for the banks: 16 entries x 8 B (two units as float2, ds_read_b64)
+// span exactly 32 banks, so lanes reading 16 different 2-mers never conflict (a 256-entry 4-mer
+// table read at random addresses would be ~3-4-way conflicted and give the gain back).
+// A lane owns one sequence and TWO units; the 2-mer index is 4 consecutive bits of the lane's
+// 2-bit packed sequence, taken from a 96-bit register window that slides 14 bits per pooling window.
+// Windows that contain an N (all-zero column) are rare; they take the per-tap table W[j][code]
+// (code 4 = zeros) instead, decided per wavefront and per window.
 // BatchNorm+exp are monotone per unit, so the 7-wide max-pool runs on the raw gather sums with the
 // sign of alpha = gamma1/sigma1 choosing max or min; only the pooled extreme (and its offset, for
 // the backward routing) leaves the kernel: ext[u][w][b], idx[u][w][b].
 #include "common.h"
 
+// LUT[pair][t][code4] = (W[u0][c0][2t] + W[u0][c1][2t+1], same for u1), c_i = (code4 >> 2i) & 3
+__global__ __launch_bounds__(256) void lut_kernel(const float* __restrict__ Wt,
+                                                  float2* __restrict__ lut, int k, int NT, int npairs) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= npairs * NT * 16) return;
+    const int code4 = e & 15, t = (e >> 4) % NT, pair = (e >> 4) / NT;
+    const int quad = pair >> 1, off = (pair & 1) * 2;
+    float s0 = 0.f, s1 = 0.f;
+    for (int i = 0; i < 2; ++i) {
+        const int j = 2 * t + i;
+        if (j < k) {
+            const float* w = Wt + ((size_t)quad * k + j) * 20 + ((code4 >> (2 * i)) & 3) * 4 + off;
+            s0 += w[0];
+            s1 += w[1];
+        }
+    }
+    lut[e] = make_float2(s0, s1);
+}
+
+// byte offset (x8) of the 2-mer starting x bases into the window; x is compile-time after unrolling
+__device__ __forceinline__ uint32_t dimer_off(uint32_t w0, uint32_t w1, uint32_t w2, int x) {
+    const int bit = 2 * x;
+    uint32_t v;
+    if (bit + 4 <= 32) v = w0 >> bit;
+    else if (bit >= 32 && bit + 4 <= 64) v = w1 >> (bit - 32);
+    else if (bit >= 64) v = w2 >> (bit - 64);
+    else if (bit < 32) v = __funnelshift_r(w0, w1, bit);
+    else v = __funnelshift_r(w1, w2, bit - 32);
+    return (v & 0xfu) * 8u;
+}
+
 template <int K>
-__global__ __launch_bounds__(64) void conv_pool_kernel(const uint8_t* __restrict__ codesT,
+__global__ __launch_bounds__(64) void conv_pool_kernel(const uint32_t* __restrict__ pk2,
+                                                       const uint32_t* __restrict__ nmask,
+                                                       const float2* __restrict__ lut,
                                                        const float* __restrict__ Wt,
                                                        const float* __restrict__ alpha,
                                                        float* __restrict__ ext,
-                                                       uint8_t* __restrict__ idx, int n, int Bs) {
-    __shared__ float4 W[K * 5];
-    const int quad = blockIdx.y, lane = threadIdx.x;
+                                                       uint8_t* __restrict__ idx, int n, int Bs,
+                                                       int PW, int NW) {
+    constexpr int NT = (K + 1) / 2;             // 2-mer tables
+    constexpr int NX = POOLW + 2 * (NT - 1);    // distinct 2-mer start offsets inside a window
+    constexpr int SPAN = POOLW + K - 1;         // positions a pooling window reads
+    extern __shared__ __attribute__((aligned(16))) uint32_t csm[];
+    float2* L2 = reinterpret_cast<float2*>(csm);            // [NT][16]
+    float2* Wp = L2 + NT * 16;                              // [K][5]   per-tap table (N path)
+    uint32_t* pks = reinterpret_cast<uint32_t*>(Wp + K * 5); // [PW][64]
+    uint32_t* nms = pks + (size_t)PW * 64;                   // [NW][64]
+    const int pair = blockIdx.y, lane = threadIdx.x;
     const int b = blockIdx.x * 64 + lane;
-    const float4* src = reinterpret_cast<const float4*>(Wt) + (size_t)quad * K * 5;
-    for (int i = lane; i < K * 5; i += 64) W[i] = src[i];
-    float sgn[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) sgn[i] = alpha[quad * 4 + i] >= 0.f ? 1.f : -1.f;
+    const int quad = pair >> 1, off = (pair & 1) * 2;
+    {
+        const float2* src = lut + (size_t)pair * NT * 16;
+        for (int i = lane; i < NT * 16; i += 64) L2[i] = src[i];
+        for (int i = lane; i < K * 5; i += 64) {
+            const float* w = Wt + ((size_t)quad * K + i / 5) * 20 + (i % 5) * 4 + off;
+            Wp[i] = make_float2(w[0], w[1]);
+        }
+        for (int w = 0; w < PW; ++w) pks[w * 64 + lane] = pk2[(size_t)w * Bs + b];
+        for (int w = 0; w < NW; ++w) nms[w * 64 + lane] = nmask[(size_t)w * Bs + b];
+    }
+    const float sg0 = alpha[pair * 2] >= 0.f ? 1.f : -1.f;
+    const float sg1 = alpha[pair * 2 + 1] >= 0.f ? 1.f : -1.f;
     __syncthreads();
-    constexpr int WIN = POOLW + K - 1;
-    int coff[WIN];
-    const uint8_t* cp = codesT + b;
-#pragma unroll
-    for (int i = 0; i < K - 1; ++i) coff[i] = (int)cp[(size_t)i * Bs] * 16;
-    const char* Wb = reinterpret_cast<const char*>(W);
+    const char* Lb = reinterpret_cast<const char*>(L2);
+    const char* Wb = reinterpret_cast<const char*>(Wp);
+    const uint32_t* pl = pks + lane;
+    const uint32_t* nl = nms + lane;
+    // window words for pooling window 0 (prefetched one window ahead inside the loop)
+    uint32_t c0 = pl[0], c1 = pl[64], c2 = pl[128], c3 = pl[192];
+    uint32_t m0 = nl[0], m1 = nl[64], m2 = nl[128];
     for (int w = 0; w < n; ++w) {
+        const int p0 = POOLW * w;
+        const int sh = (p0 & 15) * 2, nsh = p0 & 31;
+        const uint32_t w0 = __funnelshift_r(c0, c1, sh), w1 = __funnelshift_r(c1, c2, sh),
+                       w2 = __funnelshift_r(c2, c3, sh);
+        const uint32_t nm0 = __funnelshift_r(m0, m1, nsh), nm1 = __funnelshift_r(m1, m2, nsh);
+        {   // prefetch the next window's words (rows past the sequence end are zero padding)
+            const int q0 = p0 + POOLW, wi = q0 >> 4, ni = q0 >> 5;
+            c0 = pl[wi * 64]; c1 = pl[(wi + 1) * 64]; c2 = pl[(wi + 2) * 64]; c3 = pl[(wi + 3) * 64];
+            m0 = nl[ni * 64]; m1 = nl[(ni + 1) * 64]; m2 = nl[(ni + 2) * 64];
+        }
+        constexpr uint32_t HIMASK = SPAN > 32 ? ((SPAN >= 64) ? 0xffffffffu : ((1u << (SPAN - 32)) - 1u)) : 0u;
+        constexpr uint32_t LOMASK = SPAN >= 32 ? 0xffffffffu : ((1u << SPAN) - 1u);
+        const bool hasN = ((nm0 & LOMASK) | (nm1 & HIMASK)) != 0u;
+        float2 acc[POOLW];
 #pragma unroll
-        for (int i = 0; i < POOLW; ++i)
-            coff[K - 1 + i] = (int)cp[(size_t)(POOLW * w + K - 1 + i) * Bs] * 16;
-        float4 acc[POOLW];
+        for (int i = 0; i < POOLW; ++i) acc[i] = make_float2(0.f, 0.f);
+        if (!__any(hasN)) {
+            uint32_t a8[NX];
 #pragma unroll
-        for (int i = 0; i < POOLW; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int x = 0; x < NX; ++x) a8[x] = dimer_off(w0, w1, w2, x);
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
+            for (int t = 0; t < NT; ++t) {
 #pragma unroll
-            for (int i = 0; i < POOLW; ++i) {
-                const float4 v = *reinterpret_cast<const float4*>(Wb + j * 80 + coff[i + j]);
-                acc[i].x += v.x; acc[i].y += v.y; acc[i].z += v.z; acc[i].w += v.w;
+                for (int i = 0; i < POOLW; ++i) {
+                    const float2 v = *reinterpret_cast<const float2*>(Lb + t * 128 + a8[i + 2 * t]);
+                    acc[i].x += v.x; acc[i].y += v.y;
+                }
+            }
+        } else {
+            // per-tap path: code 4 (N) selects the zero entry
+            uint32_t co[SPAN];
+#pragma unroll
+            for (int x = 0; x < SPAN; ++x) {
+                const int bit = 2 * x;
+                const uint32_t c = (bit < 32 ? (w0 >> bit) : (bit < 64 ? (w1 >> (bit - 32)) : (w2 >> (bit - 64)))) & 3u;
+                const uint32_t isn = (x < 32 ? (nm0 >> x) : (nm1 >> (x - 32))) & 1u;
+                co[x] = (isn ? 4u : c) * 8u;
+            }
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+#pragma unroll
+                for (int i = 0; i < POOLW; ++i) {
+                    const float2 v = *reinterpret_cast<const float2*>(Wb + j * 40 + co[i + j]);
+                    acc[i].x += v.x; acc[i].y += v.y;
+                }
             }
         }
+        float best0 = sg0 * acc[0].x, best1 = sg1 * acc[0].y;
+        int bi0 = 0, bi1 = 0;
 #pragma unroll
-        for (int uu = 0; uu < 4; ++uu) {
-            const float sg = sgn[uu];
-            float best = sg * (uu == 0 ? acc[0].x : uu == 1 ? acc[0].y : uu == 2 ? acc[0].z : acc[0].w);
-            int bi = 0;
-#pragma unroll
-            for (int i = 1; i < POOLW; ++i) {
-                const float v = sg * (uu == 0 ? acc[i].x : uu == 1 ? acc[i].y : uu == 2 ? acc[i].z : acc[i].w);
-                if (v > best) { best = v; bi = i; }          // strict: first index wins ties
-            }
-            const size_t o = ((size_t)(quad * 4 + uu) * n + w) * Bs + b;
-            ext[o] = sg * best;
-            idx[o] = (uint8_t)bi;
+        for (int i = 1; i < POOLW; ++i) {
+            const float v0 = sg0 * acc[i].x, v1 = sg1 * acc[i].y;
+            if (v0 > best0) { best0 = v0; bi0 = i; }           // strict: first index wins ties
+            if (v1 > best1) { best1 = v1; bi1 = i; }
         }
-#pragma unroll
-        for (int i = 0; i < K - 1; ++i) coff[i] = coff[i + POOLW];
+        const size_t o0 = ((size_t)(pair * 2) * n + w) * Bs + b, o1 = o0 + (size_t)n * Bs;
+        ext[o0] = sg0 * best0; idx[o0] = (uint8_t)bi0;
+        ext[o1] = sg1 * best1; idx[o1] = (uint8_t)bi1;
     }
 }
 
@@ -83,14 +166,37 @@ __global__ __launch_bounds__(64) void conv_pool_kernel(const uint8_t* __restrict
                  return EXPLAINN_E_UNSUPPORTED;                                                \
     }
 
+static size_t conv_pool_lds(const explainn_ctx* c) {
+    const int NT = (c->k + 1) / 2;
+    return (size_t)(NT * 16 + c->k * 5) * sizeof(float2) + (size_t)(c->PW + c->NW) * 64 * 4;
+}
+
 int launch_conv_pool(explainn_ctx* c, int B, hipStream_t s) {
-    const dim3 grid((B + 63) / 64, c->Uq);
-#define CALL(KK)                                                                             \
-    hipLaunchKernelGGL(conv_pool_kernel<KK>, grid, dim3(64), 0, s, c->codesT, c->Wt, c->alpha, \
-                       c->ext, c->idx, c->n, c->Bs)
+    const int NT = (c->k + 1) / 2, npairs = c->U4 / 2;
+    hipLaunchKernelGGL(lut_kernel, dim3((npairs * NT * 16 + 255) / 256), dim3(256), 0, s, c->Wt,
+                       reinterpret_cast<float2*>(c->lut), c->k, NT, npairs);
+    LAUNCH_CHECK();
+    const dim3 grid((B + 63) / 64, c->U4 / 2);
+    const size_t sm = conv_pool_lds(c);
+#define CALL(KK)                                                                               \
+    hipLaunchKernelGGL(conv_pool_kernel<KK>, grid, dim3(64), sm, s, c->pk2, c->nmask,          \
+                       reinterpret_cast<const float2*>(c->lut), c->Wt, c->alpha, c->ext, c->idx, \
+                       c->n, c->Bs, c->PW, c->NW)
     K_DISPATCH(c->k, CALL);
 #undef CALL
     LAUNCH_CHECK();
+    return EXPLAINN_OK;
+}
+
+int conv_configure(explainn_ctx* c) {
+    const size_t sm = conv_pool_lds(c);
+    if (sm > 48 * 1024) {
+#define CALL(KK)                                                                            \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pool_kernel<KK>),   \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm))
+        K_DISPATCH(c->k, CALL);
+#undef CALL
+    }
     return EXPLAINN_OK;
 }
 

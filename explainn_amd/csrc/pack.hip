@@ -119,11 +119,13 @@ int launch_pack(explainn_ctx* c, const float* x, int B, bool counts, hipStream_t
     hipLaunchKernelGGL(pack_onehot_kernel, dim3(gb, (c->L + 63) / 64), dim3(256), 0, s, x,
                        c->codesT, B, c->L, c->Bs, c->flags);
     LAUNCH_CHECK();
-    if (counts) {
+    {
         const int bp = gb * 64;
         hipLaunchKernelGGL(pack_bits_kernel, dim3((bp + 255) / 256, c->NW), dim3(256),
                            0, s, c->codesT, c->pk2, c->nmask, c->L, c->Bs, c->PW, c->NW);
         LAUNCH_CHECK();
+    }
+    if (counts) {
         const int waves = c->k * c->L;
         hipLaunchKernelGGL(pair_counts_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, c->codesT,
                            c->cnt, B, c->L, c->k, c->Bs);
