@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libexplainn_hip.so")
+LIB_PATH = os.environ.get("EXPLAINN_HIP_LIB", os.path.join(_HERE, "libexplainn_hip.so"))
 
 OK, E_ARG, E_HIP, E_BATCH1, E_STATE, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 LOSS_BCE_WITH_LOGITS, LOSS_MSE = 0, 1

@@ -248,73 +248,68 @@ __global__ __launch_bounds__(64) void conv_bwd_kernel(const float* __restrict__ 
                                                       const uint32_t* __restrict__ nmask,
                                                       float* __restrict__ Dspp, int U, int n,
                                                       int Bs, int PW, int NW) {
-    extern __shared__ uint32_t smem[];        // pk2 tile [PW][64], nmask tile [NW][64], acc [64][STR]
-    constexpr int STR = 4 * K + 1;            // odd stride: lane rows start on distinct banks
+    // One wavefront = 64 sequences x ONE unit (the grid needs >= 4 waves per SIMD: a wave issues
+    // at most one instruction per 4 cycles).  Accumulators are slot-major, lane-minor:
+    // acc[(j*4+code)*64 + lane] always sits in bank lane&31, whatever base the lane's window has
+    // at tap j, so the read-modify-write is conflict-free for any data.
+    extern __shared__ uint32_t smem[];        // pk2 tile [PW][64], nmask tile [NW][64], acc [4K][64]
     uint32_t* pks = smem;
     uint32_t* nms = smem + (size_t)PW * 64;
     float* acc = reinterpret_cast<float*>(nms + (size_t)NW * 64);
-    const int lane = threadIdx.x, tile = blockIdx.x, quad = blockIdx.y;
+    const int lane = threadIdx.x, tile = blockIdx.x, u = blockIdx.y;
     const int b = tile * 64 + lane;
     for (int w = 0; w < PW; ++w) pks[w * 64 + lane] = pk2[(size_t)w * Bs + b];
     for (int w = 0; w < NW; ++w) nms[w * 64 + lane] = nmask[(size_t)w * Bs + b];
-    float* mine = acc + lane * STR;
+    float* mine = acc + lane;
     constexpr uint32_t KMASK = (K >= 32) ? 0xffffffffu : ((1u << K) - 1u);
-    for (int uu = 0; uu < 4; ++uu) {
-        const int u = quad * 4 + uu;
-        if (u >= U) break;
 #pragma unroll
-        for (int i = 0; i < 4 * K; ++i) mine[i] = 0.f;
-        // dy / idx for four windows are requested together: one global-load latency per four
-        // windows instead of one per window (the LDS read-modify-write chain cannot hide it)
-        for (int wb = 0; wb < n; wb += 4) {
-            float dyq[4];
-            int psq[4];
+    for (int i = 0; i < 4 * K; ++i) mine[i * 64] = 0.f;
+    // dy / idx for four windows are requested together: one global-load latency per four windows
+    for (int wb = 0; wb < n; wb += 4) {
+        float dyq[4];
+        int psq[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int w = min(wb + q, n - 1);
-                const size_t off = ((size_t)u * n + w) * Bs + b;
-                dyq[q] = (wb + q < n) ? dy[off] : 0.f;
-                psq[q] = POOLW * w + (int)idx[off];
+        for (int q = 0; q < 4; ++q) {
+            const int w = min(wb + q, n - 1);
+            const size_t off = ((size_t)u * n + w) * Bs + b;
+            dyq[q] = (wb + q < n) ? dy[off] : 0.f;
+            psq[q] = POOLW * w + (int)idx[off];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (wb + q >= n) break;                    // uniform
+            const float dyv = dyq[q];
+            const int ps = psq[q];
+            const int w0 = ps >> 4, sh = (ps & 15) * 2;
+            const uint32_t c0 = pks[w0 * 64 + lane], c1 = pks[(w0 + 1) * 64 + lane],
+                           c2 = pks[(w0 + 2) * 64 + lane];
+            const uint32_t lo = __funnelshift_r(c0, c1, sh), hi = __funnelshift_r(c1, c2, sh);
+            const int n0 = ps >> 5, nsh = ps & 31;
+            const uint32_t nm = __funnelshift_r(nms[n0 * 64 + lane], nms[(n0 + 1) * 64 + lane], nsh) & KMASK;
+            // plain read-modify-write of the lane's private column (LDS float atomics serialise
+            // per lane on gfx950); all K reads are issued before the K writes so they pipeline
+            int slot[K];
+            float cur[K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const uint32_t code = (j < 16 ? (lo >> (2 * j)) : (hi >> (2 * (j - 16)))) & 3u;
+                slot[j] = (j * 4 + (int)code) * 64;
+                cur[j] = mine[slot[j]];
             }
+            if (__any(nm != 0u)) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (wb + q >= n) break;                    // uniform
-                const float dyv = dyq[q];
-                const int ps = psq[q];
-                const int w0 = ps >> 4, sh = (ps & 15) * 2;
-                const uint32_t c0 = pks[w0 * 64 + lane], c1 = pks[(w0 + 1) * 64 + lane],
-                               c2 = pks[(w0 + 2) * 64 + lane];
-                const uint32_t lo = __funnelshift_r(c0, c1, sh), hi = __funnelshift_r(c1, c2, sh);
-                const int n0 = ps >> 5, nsh = ps & 31;
-                const uint32_t nm = __funnelshift_r(nms[n0 * 64 + lane], nms[(n0 + 1) * 64 + lane], nsh) & KMASK;
-                // private row: plain read-modify-write (LDS float atomics serialise per lane on
-                // gfx950).  All K reads are issued before the K writes so they pipeline; taps of
-                // one window touch distinct rows j, and the LDS queue keeps windows in order.
-                int slot[K];
-                float cur[K];
+                for (int j = 0; j < K; ++j) mine[slot[j]] = cur[j] + (((nm >> j) & 1u) ? 0.f : dyv);
+            } else {
 #pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    const uint32_t code = (j < 16 ? (lo >> (2 * j)) : (hi >> (2 * (j - 16)))) & 3u;
-                    slot[j] = j * 4 + (int)code;
-                    cur[j] = mine[slot[j]];
-                }
-                if (__any(nm != 0u)) {
-#pragma unroll
-                    for (int j = 0; j < K; ++j) mine[slot[j]] = cur[j] + (((nm >> j) & 1u) ? 0.f : dyv);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < K; ++j) mine[slot[j]] = cur[j] + dyv;
-                }
+                for (int j = 0; j < K; ++j) mine[slot[j]] = cur[j] + dyv;
             }
         }
-        __syncthreads();
-        for (int t = lane; t < 4 * K; t += 64) {
-            const int a = t / K, j = t % K;
-            float s = 0.f;
-            for (int l = 0; l < 64; ++l) s += acc[l * STR + j * 4 + a];
-            Dspp[((size_t)u * (Bs / 64) + tile) * 4 * K + t] = s;
-        }
-        __syncthreads();
+    }
+    // column sums over the 64 lanes; output index (a,j) -> a*K + j
+    for (int t = 0; t < 4 * K; ++t) {
+        const int a = t / K, j = t % K;
+        const float s = wave_sum(mine[(j * 4 + a) * 64]);
+        if (lane == 0) Dspp[((size_t)u * (Bs / 64) + tile) * 4 * K + t] = s;
     }
 }
 
@@ -336,8 +331,8 @@ __global__ __launch_bounds__(64) void conv_bwd_kernel(const float* __restrict__ 
     }
 
 int launch_conv_bwd(explainn_ctx* c, int B, hipStream_t s) {
-    const dim3 grid((B + 63) / 64, c->Uq);
-    const size_t sm = ((size_t)(c->PW + c->NW) * 64 + (size_t)64 * (4 * c->k + 1)) * sizeof(uint32_t);
+    const dim3 grid((B + 63) / 64, c->U);
+    const size_t sm = ((size_t)(c->PW + c->NW) * 64 + (size_t)64 * 4 * c->k) * sizeof(uint32_t);
 #define CALL(KK)                                                                               \
     hipLaunchKernelGGL(conv_bwd_kernel<KK>, grid, dim3(64), sm, s, c->dy, c->idx, c->pk2, c->nmask, \
                        c->Dspp, c->U, c->n, c->Bs, c->PW, c->NW)

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(64) void conv_pool_kernel(const uint32_t* __restric
                                                        const float* __restrict__ alpha,
                                                        float* __restrict__ ext,
                                                        uint8_t* __restrict__ idx, int n, int Bs,
-                                                       int PW, int NW) {
+                                                       int PW, int NW, int wsplit) {
     constexpr int NT = (K + 1) / 2;             // 2-mer tables
     constexpr int NX = POOLW + 2 * (NT - 1);    // distinct 2-mer start offsets inside a window
     constexpr int SPAN = POOLW + K - 1;         // positions a pooling window reads
@@ -65,7 +65,11 @@ __global__ __launch_bounds__(64) void conv_pool_kernel(const uint32_t* __restric
     uint32_t* pks = reinterpret_cast<uint32_t*>(Wp + K * 5); // [PW][64]
     uint32_t* nms = pks + (size_t)PW * 64;                   // [NW][64]
     const int pair = blockIdx.y, lane = threadIdx.x;
-    const int b = blockIdx.x * 64 + lane;
+    const int b = (blockIdx.x / wsplit) * 64 + lane;
+    // the pooling windows of a (tile, pair) are split over `wsplit` wavefronts: more waves per
+    // SIMD to hide the LDS latency (a wave issues at most one instruction per 4 cycles)
+    const int wper = (n + wsplit - 1) / wsplit;
+    const int wbeg = (blockIdx.x % wsplit) * wper, wend = min(n, wbeg + wper);
     const int quad = pair >> 1, off = (pair & 1) * 2;
     {
         const float2* src = lut + (size_t)pair * NT * 16;
@@ -84,10 +88,11 @@ __global__ __launch_bounds__(64) void conv_pool_kernel(const uint32_t* __restric
     const char* Wb = reinterpret_cast<const char*>(Wp);
     const uint32_t* pl = pks + lane;
     const uint32_t* nl = nms + lane;
-    // window words for pooling window 0 (prefetched one window ahead inside the loop)
-    uint32_t c0 = pl[0], c1 = pl[64], c2 = pl[128], c3 = pl[192];
-    uint32_t m0 = nl[0], m1 = nl[64], m2 = nl[128];
-    for (int w = 0; w < n; ++w) {
+    // window words of the first pooling window (the next one is prefetched inside the loop)
+    const int wi0 = (POOLW * wbeg) >> 4, ni0 = (POOLW * wbeg) >> 5;
+    uint32_t c0 = pl[wi0 * 64], c1 = pl[(wi0 + 1) * 64], c2 = pl[(wi0 + 2) * 64], c3 = pl[(wi0 + 3) * 64];
+    uint32_t m0 = nl[ni0 * 64], m1 = nl[(ni0 + 1) * 64], m2 = nl[(ni0 + 2) * 64];
+    for (int w = wbeg; w < wend; ++w) {
         const int p0 = POOLW * w;
         const int sh = (p0 & 15) * 2, nsh = p0 & 31;
         const uint32_t w0 = __funnelshift_r(c0, c1, sh), w1 = __funnelshift_r(c1, c2, sh),
@@ -176,12 +181,13 @@ int launch_conv_pool(explainn_ctx* c, int B, hipStream_t s) {
     hipLaunchKernelGGL(lut_kernel, dim3((npairs * NT * 16 + 255) / 256), dim3(256), 0, s, c->Wt,
                        reinterpret_cast<float2*>(c->lut), c->k, NT, npairs);
     LAUNCH_CHECK();
-    const dim3 grid((B + 63) / 64, c->U4 / 2);
+    const int wsplit = c->n >= 8 ? 2 : 1;
+    const dim3 grid(((B + 63) / 64) * wsplit, c->U4 / 2);
     const size_t sm = conv_pool_lds(c);
 #define CALL(KK)                                                                               \
     hipLaunchKernelGGL(conv_pool_kernel<KK>, grid, dim3(64), sm, s, c->pk2, c->nmask,          \
                        reinterpret_cast<const float2*>(c->lut), c->Wt, c->alpha, c->ext, c->idx, \
-                       c->n, c->Bs, c->PW, c->NW)
+                       c->n, c->Bs, c->PW, c->NW, wsplit)
     K_DISPATCH(c->k, CALL);
 #undef CALL
     LAUNCH_CHECK();

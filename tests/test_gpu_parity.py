@@ -115,7 +115,15 @@ def test_train_with_reference_dropout_mask(golden):
 
 def test_adam_trajectory_golden(golden):
     """20 optimiser steps (torch.optim.Adam on our parameters, our gradients): per-step train-mode
-    logits/loss and the learned filters stay within tolerance of the reference's trajectory."""
+    logits/loss and the learned filters stay within tolerance of the reference's trajectory.
+
+    The gradient is discontinuous where a ReLU pre-activation crosses zero.  When some |y2| or |y3|
+    is below 2e-6 at a step (found with the oracle at the model's own parameters), two fp32
+    implementations may legitimately take different branches there and their trajectories part by
+    a finite amount (seen: |y2| = 3.9e-7 at step 12 of small_u8_k19_mse; a single flip is 1/(100 B)
+    of a unit's gradient, visible only in the small fixtures).  The run must follow the reference
+    unless such a step has occurred; after leaving it, only single-step parity (logits vs the
+    oracle at the same parameters) is asserted."""
     g = golden
     from explainn_amd import get_optimizer
     m = _model(g.sd(), g.U, g.k, g.L, g.T)
@@ -125,21 +133,40 @@ def test_adam_trajectory_golden(golden):
     n_steps = len(g.z["steps/loss"])
     if g.B <= 2:
         n_steps = 2           # see tests/test_oracle_golden.py
+    knife_edge = None          # first step with a ReLU pre-activation within 2e-6 of zero
+    following = True           # still on the reference's trajectory
+    followed = 0
     for step in range(1, n_steps + 1):
         i = (step - 1) % g.n_batches
-        x = torch.from_numpy(g.onehot(i)).cuda()
+        xn = g.onehot(i)
+        x = torch.from_numpy(xn).cuda()
         y = torch.from_numpy(g.targets(i).astype(np.float32)).cuda()
+        sd_now = {k: _np(v) for k, v in m.state_dict().items()}
+        ref_logits, cache, _ = orc.forward(sd_now, xn, training=True, return_cache=True)
         m.train()
         pred = m(x)
         loss = crit(pred, y)
         opt.zero_grad(); loss.backward(); opt.step()
-        _close(loss.item(), g.z["steps/loss"][step - 1], tol=2e-5, what="loss step %d" % step)
-        _close(_np(pred), g.z["steps/logits"][step - 1], what="logits step %d" % step)
-        ref = g.group("step%d/sd/" % step)
-        sd = m.state_dict()
-        for k in ("linears.0.weight", "final.weight", "final.bias", "linears.11.weight"):
-            if k in ref:
-                _close(_np(sd[k]), ref[k], tol=2e-4, what="step %d %s" % (step, k))
+        _close(_np(pred), ref_logits, what="logits vs oracle at own parameters, step %d" % step)
+        if following:
+            try:
+                _close(loss.item(), g.z["steps/loss"][step - 1], tol=2e-5, what="loss step %d" % step)
+                _close(_np(pred), g.z["steps/logits"][step - 1], what="logits step %d" % step)
+                ref = g.group("step%d/sd/" % step)
+                sd = m.state_dict()
+                for k in ("linears.0.weight", "final.weight", "final.bias", "linears.11.weight"):
+                    if k in ref:
+                        _close(_np(sd[k]), ref[k], tol=2e-4, what="step %d %s" % (step, k))
+                followed = step
+            except AssertionError:
+                # leaving the reference trajectory is only acceptable after a knife-edge step
+                assert knife_edge is not None and knife_edge < step, \
+                    "left the reference trajectory at step %d without a ReLU knife-edge" % step
+                following = False
+        margin = min(np.abs(cache["y2"]).min(), np.abs(cache["y3"]).min())
+        if margin < 2e-6 and knife_edge is None:
+            knife_edge = step
+    assert followed >= min(n_steps, 3), "trajectory left the reference after %d steps" % followed
 
 
 @pytest.mark.parametrize("U,k,L,T,B,nfrac", [
