@@ -47,7 +47,7 @@ void carve(explainn_ctx* c, Carver& cv) {
     cv.take(&c->lut, (int64_t)(c->U4 / 2) * ((c->k + 1) / 2) * 32);
     cv.take(&c->ext, U4 * n * Bs);
     cv.take(&c->idx, U4 * n * Bs);
-    cv.take(&c->qbw, (U * Bs + 2) * NS);
+    cv.take(&c->qbw, 64);                              // (sequence-major q copy: no longer used)
     cv.take(&c->qs0, U * NS);
     cv.take(&c->qS1p, U * c->QCH * NS);
     cv.take(&c->qS2p, U * c->QCH * NS * NS);

@@ -248,22 +248,23 @@ __global__ __launch_bounds__(64) void conv_bwd_kernel(const float* __restrict__ 
                                                       const uint32_t* __restrict__ nmask,
                                                       float* __restrict__ Dspp, int U, int n,
                                                       int Bs, int PW, int NW) {
-    // One wavefront = 64 sequences x ONE unit (the grid needs >= 4 waves per SIMD: a wave issues
-    // at most one instruction per 4 cycles).  Accumulators are slot-major, lane-minor:
-    // acc[(j*4+code)*64 + lane] always sits in bank lane&31, whatever base the lane's window has
-    // at tap j, so the read-modify-write is conflict-free for any data.
-    extern __shared__ uint32_t smem[];        // pk2 tile [PW][64], nmask tile [NW][64], acc [4K][64]
+    // One wavefront = 64 sequences x one unit; lane = sequence.  The 4K partial sums of a lane live
+    // in REGISTERS: per tap three compare-select-adds for bases C,G,T; base A is recovered at the
+    // end as (sum of all dy) - C - G - T - (dy that fell on an N).  No LDS traffic in the loop
+    // (LDS float atomics serialise per lane on gfx950, and plain LDS read-modify-write chains
+    // were latency-bound: profiles/r01_c), ~100 VGPRs -> 5 waves per SIMD.
+    extern __shared__ uint32_t smem[];        // pk2 tile [PW][64], nmask tile [NW][64]
     uint32_t* pks = smem;
     uint32_t* nms = smem + (size_t)PW * 64;
-    float* acc = reinterpret_cast<float*>(nms + (size_t)NW * 64);
     const int lane = threadIdx.x, tile = blockIdx.x, u = blockIdx.y;
     const int b = tile * 64 + lane;
     for (int w = 0; w < PW; ++w) pks[w * 64 + lane] = pk2[(size_t)w * Bs + b];
     for (int w = 0; w < NW; ++w) nms[w * 64 + lane] = nmask[(size_t)w * Bs + b];
-    float* mine = acc + lane;
     constexpr uint32_t KMASK = (K >= 32) ? 0xffffffffu : ((1u << K) - 1u);
+    float a1[K], a2[K], a3[K], an[K];
 #pragma unroll
-    for (int i = 0; i < 4 * K; ++i) mine[i * 64] = 0.f;
+    for (int j = 0; j < K; ++j) { a1[j] = 0.f; a2[j] = 0.f; a3[j] = 0.f; an[j] = 0.f; }
+    float tot = 0.f;
     // dy / idx for four windows are requested together: one global-load latency per four windows
     for (int wb = 0; wb < n; wb += 4) {
         float dyq[4];
@@ -277,8 +278,7 @@ __global__ __launch_bounds__(64) void conv_bwd_kernel(const float* __restrict__ 
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            if (wb + q >= n) break;                    // uniform
-            const float dyv = dyq[q];
+            const float dyv = dyq[q];                  // 0 for windows past the end
             const int ps = psq[q];
             const int w0 = ps >> 4, sh = (ps & 15) * 2;
             const uint32_t c0 = pks[w0 * 64 + lane], c1 = pks[(w0 + 1) * 64 + lane],
@@ -286,30 +286,27 @@ __global__ __launch_bounds__(64) void conv_bwd_kernel(const float* __restrict__ 
             const uint32_t lo = __funnelshift_r(c0, c1, sh), hi = __funnelshift_r(c1, c2, sh);
             const int n0 = ps >> 5, nsh = ps & 31;
             const uint32_t nm = __funnelshift_r(nms[n0 * 64 + lane], nms[(n0 + 1) * 64 + lane], nsh) & KMASK;
-            // plain read-modify-write of the lane's private column (LDS float atomics serialise
-            // per lane on gfx950); all K reads are issued before the K writes so they pipeline
-            int slot[K];
-            float cur[K];
+            tot += dyv;
 #pragma unroll
             for (int j = 0; j < K; ++j) {
                 const uint32_t code = (j < 16 ? (lo >> (2 * j)) : (hi >> (2 * (j - 16)))) & 3u;
-                slot[j] = (j * 4 + (int)code) * 64;
-                cur[j] = mine[slot[j]];
+                a1[j] += (code == 1u) ? dyv : 0.f;
+                a2[j] += (code == 2u) ? dyv : 0.f;
+                a3[j] += (code == 3u) ? dyv : 0.f;
             }
-            if (__any(nm != 0u)) {
+            if (__any(nm != 0u)) {                     // N positions are packed as code 0
 #pragma unroll
-                for (int j = 0; j < K; ++j) mine[slot[j]] = cur[j] + (((nm >> j) & 1u) ? 0.f : dyv);
-            } else {
-#pragma unroll
-                for (int j = 0; j < K; ++j) mine[slot[j]] = cur[j] + dyv;
+                for (int j = 0; j < K; ++j) an[j] += ((nm >> j) & 1u) ? dyv : 0.f;
             }
         }
     }
-    // column sums over the 64 lanes; output index (a,j) -> a*K + j
-    for (int t = 0; t < 4 * K; ++t) {
-        const int a = t / K, j = t % K;
-        const float s = wave_sum(mine[(j * 4 + a) * 64]);
-        if (lane == 0) Dspp[((size_t)u * (Bs / 64) + tile) * 4 * K + t] = s;
+    // sums over the 64 lanes; output index (a,j) -> a*K + j
+    float* out = Dspp + ((size_t)u * (Bs / 64) + tile) * 4 * K;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const float s0 = wave_sum(tot - an[j] - a1[j] - a2[j] - a3[j]);
+        const float s1 = wave_sum(a1[j]), s2 = wave_sum(a2[j]), s3 = wave_sum(a3[j]);
+        if (lane == 0) { out[j] = s0; out[K + j] = s1; out[2 * K + j] = s2; out[3 * K + j] = s3; }
     }
 }
 
@@ -332,7 +329,7 @@ __global__ __launch_bounds__(64) void conv_bwd_kernel(const float* __restrict__ 
 
 int launch_conv_bwd(explainn_ctx* c, int B, hipStream_t s) {
     const dim3 grid((B + 63) / 64, c->U);
-    const size_t sm = ((size_t)(c->PW + c->NW) * 64 + (size_t)64 * 4 * c->k) * sizeof(uint32_t);
+    const size_t sm = (size_t)(c->PW + c->NW) * 64 * sizeof(uint32_t);
 #define CALL(KK)                                                                               \
     hipLaunchKernelGGL(conv_bwd_kernel<KK>, grid, dim3(64), sm, s, c->dy, c->idx, c->pk2, c->nmask, \
                        c->Dspp, c->U, c->n, c->Bs, c->PW, c->NW)

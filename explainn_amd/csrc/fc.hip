@@ -161,71 +161,101 @@ int launch_fc_fwd(explainn_ctx* c, const explainn_params* p, int B, bool train,
 }
 
 // ---------------------------------------------------------------------------------------------
-// passA: one wavefront per (unit, batch chunk); K dimension = sequences, two per MFMA
+// passA: one wavefront per (unit, batch chunk, w-tile); K dimension = sequences, two per MFMA.
+// Super-tiles of 64 sequences are fetched with coalesced loads (lane = sequence): the q rows
+// (from ext, through exp), the 128 bit words and dz; they are re-read from a wave-private LDS tile
+// in MFMA operand order while the next super-tile's loads are already in flight.
 // ---------------------------------------------------------------------------------------------
+#define QT_LD 65
 template <int NQ>
-__global__ __launch_bounds__(64) void passA_kernel(const float* __restrict__ qbw,
+__global__ __launch_bounds__(64) void passA_kernel(const float* __restrict__ ext,
+                                                   const float* __restrict__ alpha,
+                                                   const float* __restrict__ shift,
                                                    const float* __restrict__ dz,
                                                    const uint4* __restrict__ bits,
                                                    float* __restrict__ EQp,
                                                    float* __restrict__ Sep, int n, int Bs, int B,
                                                    int ACH) {
-    constexpr int NS = ns_stride(NQ), NWT = (NQ + 31) / 32;
-    const int u = blockIdx.y, ch = blockIdx.x, lane = threadIdx.x;
+    constexpr int NS = ns_stride(NQ);
+    __shared__ float tq[32 * QT_LD];
+    __shared__ __attribute__((aligned(16))) uint4 tw[64];
+    __shared__ float tdz[64];
+    const int u = blockIdx.y, ch = blockIdx.x, wt = blockIdx.z, lane = threadIdx.x;
     const int rc = lane & 31, kk = lane >> 5;
-    const int per = (((B + ACH - 1) / ACH) + 1) & ~1;          // even: whole k-steps
+    const int per = ((((B + ACH - 1) / ACH) + 63) / 64) * 64;
     const int bbeg = ch * per, bend = min(B, bbeg + per);
+    const float a1 = alpha[u], sh1 = shift[u];
+    const float* eu = ext + (size_t)u * n * Bs;
     const float* dzu = dz + (size_t)u * Bs;
     const uint4* bu = bits + (size_t)u * Bs;
-    const float* qu = qbw + (size_t)u * Bs * NS;
+    f32x16 acc[FC_RT];
+#pragma unroll
+    for (int t = 0; t < FC_RT; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc[t][g] = 0.f;
     float se[FC_RT] = {0.f, 0.f, 0.f, 0.f};
-    for (int wt = 0; wt < NWT; ++wt) {
-        const int w = wt * 32 + rc;
-        f32x16 acc[FC_RT];
+    float rq[32], rdz = 0.f;
+    uint4 rw = make_uint4(0u, 0u, 0u, 0u);
+    auto fetch = [&](int b0) {
+        const int b = b0 + lane;
+        const bool live = b < bend;
+        const int bc = live ? b : bbeg;
 #pragma unroll
-        for (int t = 0; t < FC_RT; ++t)
+        for (int i = 0; i < 32; ++i) {
+            const int w = wt * 32 + i;
+            rq[i] = (live && w < n) ? qval(a1, eu[(size_t)w * Bs + bc], sh1) : 0.f;
+        }
+        rdz = live ? dzu[bc] : 0.f;
+        rw = bu[bc];
+    };
+    if (bbeg < bend) fetch(bbeg);
+    for (int b0 = bbeg; b0 < bend; b0 += 64) {
 #pragma unroll
-            for (int g = 0; g < 16; ++g) acc[t][g] = 0.f;
-#pragma unroll 8
-        for (int b0 = bbeg; b0 < bend; b0 += 2) {
-            const int b = b0 + kk;
-            const bool live = b < bend;
-            const int bc = live ? b : bbeg;
-            const float qv = (live && w < NS) ? qu[(size_t)bc * NS + w] : 0.f;
-            const float dzb = live ? dzu[bc] : 0.f;
-            const uint4 wv = bu[bc];
+        for (int i = 0; i < 32; ++i) tq[i * QT_LD + lane] = rq[i];
+        tw[lane] = rw;
+        tdz[lane] = rdz;
+        if (b0 + 64 < bend) fetch(b0 + 64);           // in flight during the MFMAs below
+        const int ks = (min(bend - b0, 64) + 1) >> 1;
+        for (int s = 0; s < ks; ++s) {
+            const int col = 2 * s + kk;
+            const float qv = tq[rc * QT_LD + col];
+            const float dzb = tdz[col];
+            const uint4 wv = tw[col];
             const uint32_t wds[FC_RT] = {wv.x, wv.y, wv.z, wv.w};
 #pragma unroll
             for (int t = 0; t < FC_RT; ++t) {
                 const float e = ((wds[t] >> rc) & 1u) ? dzb : 0.f;
-                if (wt == 0) se[t] += e;
+                se[t] += e;
                 acc[t] = MFMA32(e, qv, acc[t]);
             }
         }
-        // D[r][w]: lane holds column w = wt*32+rc, rows r = 32t + (g&3) + 8(g>>2) + 4kk
-        if (w < NS) {
-#pragma unroll
-            for (int t = 0; t < FC_RT; ++t)
-#pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    const int r = 32 * t + (g & 3) + 8 * (g >> 2) + 4 * kk;
-                    if (r < FC_H) EQp[(((size_t)u * ACH + ch) * FC_H + r) * NS + w] = acc[t][g];
-                }
-        }
     }
+    // D[r][w]: lane holds column w = wt*32+rc, rows r = 32t + (g&3) + 8(g>>2) + 4kk
+    const int w = wt * 32 + rc;
+    if (w < NS) {
 #pragma unroll
-    for (int t = 0; t < FC_RT; ++t) {
-        const float s = se[t] + __shfl_xor(se[t], 32, 64);
-        const int r = 32 * t + rc;
-        if (kk == 0 && r < FC_H) Sep[((size_t)u * ACH + ch) * FC_H + r] = s;
+        for (int t = 0; t < FC_RT; ++t)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int r = 32 * t + (g & 3) + 8 * (g >> 2) + 4 * kk;
+                if (r < FC_H) EQp[(((size_t)u * ACH + ch) * FC_H + r) * NS + w] = acc[t][g];
+            }
+    }
+    if (wt == 0) {
+#pragma unroll
+        for (int t = 0; t < FC_RT; ++t) {
+            const float sv = se[t] + __shfl_xor(se[t], 32, 64);
+            const int r = 32 * t + rc;
+            if (kk == 0 && r < FC_H) Sep[((size_t)u * ACH + ch) * FC_H + r] = sv;
+        }
     }
 }
 
 int launch_passA(explainn_ctx* c, int B, hipStream_t s) {
-    const dim3 grid(c->ACH, c->U);
-#define CALL(N)                                                                           \
-    hipLaunchKernelGGL(passA_kernel<N>, grid, dim3(64), 0, s, c->qbw, c->dz, c->bits, c->EQp, \
-                       c->Sep, c->n, c->Bs, B, c->ACH)
+#define CALL(N)                                                                                  \
+    hipLaunchKernelGGL(passA_kernel<N>, dim3(c->ACH, c->U, (N + 31) / 32), dim3(64), 0, s,       \
+                       c->ext, c->alpha, c->shift, c->dz, c->bits, c->EQp, c->Sep, c->n, c->Bs,  \
+                       B, c->ACH)
     NQ_DISPATCH(c->NQ, CALL);
 #undef CALL
     LAUNCH_CHECK();

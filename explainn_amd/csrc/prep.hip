@@ -92,88 +92,95 @@ int launch_prep1(explainn_ctx* c, const explainn_params* p, int B, bool train, h
 }
 
 // ---------------------------------------------------------------------------------------------
-// qtrans: ext [u][w][b] -> q [u][b][w] (row stride NS, zero padded), one wave per 64 sequences
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void qtrans_kernel(const float* __restrict__ ext,
-                                                    const float* __restrict__ alpha,
-                                                    const float* __restrict__ shift,
-                                                    float* __restrict__ qbw, float* __restrict__ qs0,
-                                                    int n, int NS, int Bs, int B) {
-    extern __shared__ float tile[];           // [64][NS+1]
-    const int u = blockIdx.y, b0 = blockIdx.x * 64, lane = threadIdx.x;
-    const float a = alpha[u], sh = shift[u];
-    const int ld = NS + 1;
-    for (int w = 0; w < NS; ++w) {
-        float q = 0.f;
-        if (w < n && b0 + lane < B) q = qval(a, ext[((size_t)u * n + w) * Bs + b0 + lane], sh);
-        tile[lane * ld + w] = q;
-    }
-    __syncthreads();
-    float* dst = qbw + ((size_t)u * Bs + b0) * NS;
-    for (int i = lane; i < 64 * NS; i += 64) dst[i] = tile[(i / NS) * ld + (i % NS)];
-    if (b0 == 0)
-        for (int w = lane; w < NS; w += 64) qs0[(size_t)u * NS + w] = tile[w];
-}
-
-// ---------------------------------------------------------------------------------------------
-// qmom: per (unit, batch chunk): S1[w'] = sum_b (q[b,w']-s[w']),  S2r[w][w'] = sum_b q[b,w]*(q[b,w']-s[w'])
-// lane = w'; q[b,w] is a scalar (uniform) operand
+// qmom: first/second moments of q over the batch on the exact-fp32 matrix core.
+//   S1[w'] = sum_b (q[b,w'] - s[w']),   S2r[w][w'] = sum_b q[b,w] (q[b,w'] - s[w']),  s = q of sequence 0
+// One wavefront per (unit, batch chunk, 32x32 tile of (w,w')).  The sequence index is the MFMA K
+// dimension (two sequences per v_mfma_f32_32x32x2_f32), but ext is stored batch-fastest, so each
+// super-tile of 64 sequences is fetched with coalesced row loads (lane = sequence), turned into
+// q = exp(alpha*ext+shift) and transposed through a wave-private LDS tile [row][65]; the next
+// super-tile's loads are in flight while the current one feeds the matrix core.
 // ---------------------------------------------------------------------------------------------
 typedef float f32x16q __attribute__((ext_vector_type(16)));
+#define QT_LD 65
 
-// One wavefront per (unit, batch chunk) on the exact-fp32 matrix core: S2r = Q' (Q - s), with the
-// sequence index as the K dimension (two sequences per v_mfma_f32_32x32x2_f32).
 template <int NQ>
 __global__ __launch_bounds__(64) void qmom_kernel(
-    const float* __restrict__ qbw, const float* __restrict__ qs0, float* __restrict__ S1p,
+    const float* __restrict__ ext, const float* __restrict__ alpha,
+    const float* __restrict__ shift, float* __restrict__ qs0, float* __restrict__ S1p,
     float* __restrict__ S2p, int n, int Bs, int B, int QCH) {
     constexpr int NS = ns_stride(NQ), NWT = (NQ + 31) / 32;
+    __shared__ float tA[32 * QT_LD];
+    __shared__ float tB[NWT > 1 ? 32 * QT_LD : 1];
     const int u = blockIdx.y, ch = blockIdx.x, lane = threadIdx.x;
+    const int wt = blockIdx.z / NWT, wt2 = blockIdx.z % NWT;
+    const bool same = wt == wt2;
     const int rc = lane & 31, kk = lane >> 5;
-    const int per = (((B + QCH - 1) / QCH) + 1) & ~1;
+    const int per = ((((B + QCH - 1) / QCH) + 63) / 64) * 64;
     const int bbeg = ch * per, bend = min(B, bbeg + per);
-    const float* qu = qbw + (size_t)u * Bs * NS;
-    for (int wt = 0; wt < NWT; ++wt) {
-        for (int wt2 = 0; wt2 < NWT; ++wt2) {
-            const int wA = wt * 32 + rc, wB = wt2 * 32 + rc;
-            const float sB = (wB < n) ? qs0[(size_t)u * NS + wB] : 0.f;
-            f32x16q acc;
+    const float a1 = alpha[u], sh1 = shift[u];
+    const float* eu = ext + (size_t)u * n * Bs;
+    const int wB = wt2 * 32 + rc;
+    const float sB = (wB < n) ? qval(a1, eu[(size_t)wB * Bs], sh1) : 0.f;    // q of sequence 0
+    if (ch == 0 && wt == 0 && kk == 0 && wB < NS) qs0[(size_t)u * NS + wB] = sB;
+    f32x16q acc;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) acc[g] = 0.f;
-            float s1 = 0.f;
-#pragma unroll 4
-            for (int b0 = bbeg; b0 < bend; b0 += 2) {
-                const int b = b0 + kk;
-                const bool live = b < bend;
-                const size_t row = (size_t)(live ? b : bbeg) * NS;
-                const float a = (live && wA < NS) ? qu[row + wA] : 0.f;
-                const float bq = (live && wB < n) ? qu[row + wB] - sB : 0.f;
-                s1 += bq;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc, 0, 0, 0);
-            }
-            if (wB < NS) {
+    for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+    float s1 = 0.f;
+    float ra[32], rb[NWT > 1 ? 32 : 1];
+    auto fetch = [&](int b0) {
+        const int b = b0 + lane;
+        const bool live = b < bend;
 #pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    const int w = wt * 32 + (g & 3) + 8 * (g >> 2) + 4 * kk;
-                    if (w < NS) S2p[(((size_t)u * QCH + ch) * NS + w) * NS + wB] = acc[g];
-                }
-            }
-            if (wt == 0) {
-                s1 += __shfl_xor(s1, 32, 64);
-                if (kk == 0 && wB < NS) S1p[((size_t)u * QCH + ch) * NS + wB] = s1;
+        for (int i = 0; i < 32; ++i) {
+            const int w = wt * 32 + i;
+            ra[i] = (live && w < n) ? qval(a1, eu[(size_t)w * Bs + b], sh1) : 0.f;
+        }
+        if (NWT > 1 && !same) {
+#pragma unroll
+            for (int i = 0; i < (NWT > 1 ? 32 : 1); ++i) {
+                const int w = wt2 * 32 + i;
+                rb[i] = (live && w < n) ? qval(a1, eu[(size_t)w * Bs + b], sh1) : 0.f;
             }
         }
+    };
+    if (bbeg < bend) fetch(bbeg);
+    for (int b0 = bbeg; b0 < bend; b0 += 64) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) tA[i * QT_LD + lane] = ra[i];
+        if (NWT > 1 && !same) {
+#pragma unroll
+            for (int i = 0; i < (NWT > 1 ? 32 : 1); ++i) tB[i * QT_LD + lane] = rb[i];
+        }
+        if (b0 + 64 < bend) fetch(b0 + 64);           // in flight during the MFMAs below
+        const int ks = (min(bend - b0, 64) + 1) >> 1;
+        const float* srcB = (NWT > 1 && !same) ? tB : tA;
+        for (int s = 0; s < ks; ++s) {
+            const int col = 2 * s + kk;
+            const bool live = b0 + col < bend;
+            const float a = tA[rc * QT_LD + col];
+            const float bq = (live && wB < n) ? srcB[rc * QT_LD + col] - sB : 0.f;
+            s1 += bq;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc, 0, 0, 0);
+        }
+    }
+    if (wB < NS) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int w = wt * 32 + (g & 3) + 8 * (g >> 2) + 4 * kk;
+            if (w < NS) S2p[(((size_t)u * QCH + ch) * NS + w) * NS + wB] = acc[g];
+        }
+    }
+    if (wt == 0) {
+        s1 += __shfl_xor(s1, 32, 64);
+        if (kk == 0 && wB < NS) S1p[((size_t)u * QCH + ch) * NS + wB] = s1;
     }
 }
 
 int launch_qmoments(explainn_ctx* c, int B, hipStream_t s) {
-    const int gb = (B + 63) / 64;
-    hipLaunchKernelGGL(qtrans_kernel, dim3(gb, c->U), dim3(64), 64 * (c->NS + 1) * sizeof(float), s,
-                       c->ext, c->alpha, c->shift, c->qbw, c->qs0, c->n, c->NS, c->Bs, B);
-    LAUNCH_CHECK();
 #define CALL(N)                                                                                  \
-    hipLaunchKernelGGL(qmom_kernel<N>, dim3(c->QCH, c->U), dim3(64), 0, s,     \
-                       c->qbw, c->qs0, c->qS1p, c->qS2p, c->n, c->Bs, B, c->QCH)
+    hipLaunchKernelGGL(qmom_kernel<N>, dim3(c->QCH, c->U, ((N + 31) / 32) * ((N + 31) / 32)),    \
+                       dim3(64), 0, s, c->ext, c->alpha, c->shift, c->qs0, c->qS1p, c->qS2p,     \
+                       c->n, c->Bs, B, c->QCH)
     NQ_DISPATCH(c->NQ, CALL);
 #undef CALL
     LAUNCH_CHECK();
