@@ -131,7 +131,13 @@ extern "C" int explainn_create(explainn_ctx** out, int cnn_units, int kernel_siz
     c->U = cnn_units; c->k = kernel_size; c->L = sequence_length; c->T = n_features;
     c->maxB = max_batch; c->device = device;
     c->Lo = Lo; c->n = n; c->U4 = (cnn_units + 3) & ~3; c->Uq = c->U4 / 4;
-    c->NQ = NQ; c->NS = ns_stride(NQ); c->NX = fcx_stride(NQ); c->Bs = (max_batch + 63) & ~63; c->K4 = 4 * kernel_size;
+    c->NQ = NQ; c->NS = ns_stride(NQ); c->NX = fcx_stride(NQ); c->K4 = 4 * kernel_size;
+    // Batch stride of every [..][b] array: a multiple of 64 lanes, but an ODD multiple, so that the
+    // row stride (4*Bs bytes) is never a multiple of 512 B: with Bs = 1024 every row of ext/dy/...
+    // was exactly 4096 B apart and all rows of a wavefront (and of every unit) landed on the same
+    // memory channel (channel camping: ~8 us per dependent load, profiles/r01_c).
+    c->Bs = (max_batch + 63) & ~63;
+    if (((c->Bs / 64) & 1) == 0) c->Bs += 64;
     c->NW = (sequence_length + 31) / 32 + 2; c->PW = 2 * c->NW;
     {
         int q = (max_batch + 127) / 128;
@@ -243,6 +249,18 @@ extern "C" int explainn_forward_train(explainn_ctx* c, const float* x, int B,
     return EXPLAINN_OK;
 }
 
+namespace {
+int backward_tail(explainn_ctx* c, int B, const explainn_params* p, const explainn_grads* g,
+                  int freeze_top_n_filters, hipStream_t s) {
+    TRY(launch_passA(c, B, s));
+    TRY(launch_mid_bwd(c, p, g, B, s));
+    TRY(launch_passB(c, B, s));
+    TRY(launch_conv_bwd(c, B, s));
+    TRY(launch_fin_bwd(c, p, g, B, freeze_top_n_filters, s));
+    return EXPLAINN_OK;
+}
+}  // namespace
+
 extern "C" int explainn_backward(explainn_ctx* c, const float* dlogits, int B,
                                  const explainn_params* p, const explainn_grads* g,
                                  int freeze_top_n_filters, void* stream) {
@@ -254,12 +272,7 @@ extern "C" int explainn_backward(explainn_ctx* c, const float* dlogits, int B,
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     TRY(launch_head_bwd(c, p, g, dlogits, B, s));
-    TRY(launch_passA(c, B, s));
-    TRY(launch_mid_bwd(c, p, g, B, s));
-    TRY(launch_passB(c, B, s));
-    TRY(launch_conv_bwd(c, B, s));
-    TRY(launch_fin_bwd(c, p, g, B, freeze_top_n_filters, s));
-    return EXPLAINN_OK;
+    return backward_tail(c, B, p, g, freeze_top_n_filters, s);
 }
 
 extern "C" int explainn_loss_grad(explainn_ctx* c, int loss_kind, const float* logits,
@@ -278,7 +291,17 @@ extern "C" int explainn_train_step(explainn_ctx* c, const float* x, const float*
                                    const explainn_params* p, const explainn_grads* g, int loss_kind,
                                    float dropout_p, uint64_t seed, int freeze_top_n_filters,
                                    float* logits, float* loss_out, void* stream) {
+    if (loss_kind != EXPLAINN_LOSS_BCE_WITH_LOGITS && loss_kind != EXPLAINN_LOSS_MSE) {
+        explainn_set_error("unknown loss kind %d", loss_kind);
+        return EXPLAINN_E_ARG;
+    }
     TRY(explainn_forward_train(c, x, B, p, nullptr, dropout_p, seed, logits, stream));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (c->T <= 4) {
+        // few tasks: the loss gradient is recomputed inside the head backward (one launch less)
+        TRY(launch_head_bwd_fused_loss(c, p, g, loss_kind, logits, targets, loss_out, B, s));
+        return backward_tail(c, B, p, g, freeze_top_n_filters, s);
+    }
     TRY(explainn_loss_grad(c, loss_kind, logits, targets, B, loss_out, c->dlogits, stream));
     TRY(explainn_backward(c, c->dlogits, B, p, g, freeze_top_n_filters, stream));
     return EXPLAINN_OK;

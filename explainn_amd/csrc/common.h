@@ -106,6 +106,9 @@ int launch_loss(explainn_ctx* c, int kind, const float* logits, const float* y, 
                 float* loss, float* dlogits, hipStream_t s);
 int launch_head_bwd(explainn_ctx* c, const explainn_params* p, const explainn_grads* g,
                     const float* dlogits, int B, hipStream_t s);
+int launch_head_bwd_fused_loss(explainn_ctx* c, const explainn_params* p, const explainn_grads* g,
+                               int kind, const float* logits, const float* y, float* loss_out, int B,
+                               hipStream_t s);
 int launch_passA(explainn_ctx* c, int B, hipStream_t s);
 int launch_mid_bwd(explainn_ctx* c, const explainn_params* p, const explainn_grads* g, int B,
                    hipStream_t s);
@@ -118,6 +121,21 @@ int prep_configure(explainn_ctx* c);
 int bwd_configure(explainn_ctx* c);
 int fc_configure(explainn_ctx* c);
 int conv_configure(explainn_ctx* c);
+
+// In-kernel stamps (tools/stampbench.hip defines EXPLAINN_STAMP; the library build compiles them out)
+#ifdef EXPLAINN_STAMP
+extern __device__ unsigned long long g_stamps[];
+#define STAMP(i)                                                                                  \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                               \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        if ((threadIdx.x & 63) == 0)                                                              \
+            g_stamps[((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * (blockDim.x / 64) + threadIdx.x / 64) * 8 + (i)] = t_; \
+    } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 
 // q = exp(alpha*ext + shift): every consumer must evaluate it identically
 __device__ __forceinline__ float qval(float alpha, float ext, float shift) {

@@ -16,24 +16,8 @@
 // the backward routing) leaves the kernel: ext[u][w][b], idx[u][w][b].
 #include "common.h"
 
-// LUT[pair][t][code4] = (W[u0][c0][2t] + W[u0][c1][2t+1], same for u1), c_i = (code4 >> 2i) & 3
-__global__ __launch_bounds__(256) void lut_kernel(const float* __restrict__ Wt,
-                                                  float2* __restrict__ lut, int k, int NT, int npairs) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= npairs * NT * 16) return;
-    const int code4 = e & 15, t = (e >> 4) % NT, pair = (e >> 4) / NT;
-    const int quad = pair >> 1, off = (pair & 1) * 2;
-    float s0 = 0.f, s1 = 0.f;
-    for (int i = 0; i < 2; ++i) {
-        const int j = 2 * t + i;
-        if (j < k) {
-            const float* w = Wt + ((size_t)quad * k + j) * 20 + ((code4 >> (2 * i)) & 3) * 4 + off;
-            s0 += w[0];
-            s1 += w[1];
-        }
-    }
-    lut[e] = make_float2(s0, s1);
-}
+// The tables LUT[pair][t][code4] = (W[u0][c0][2t] + W[u0][c1][2t+1], same for u1),
+// c_i = (code4 >> 2i) & 3, are written by prep1 (prep.hip) from the current filters.
 
 // byte offset (x8) of the 2-mer starting x bases into the window; x is compile-time after unrolling
 __device__ __forceinline__ uint32_t dimer_off(uint32_t w0, uint32_t w1, uint32_t w2, int x) {
@@ -177,10 +161,6 @@ static size_t conv_pool_lds(const explainn_ctx* c) {
 }
 
 int launch_conv_pool(explainn_ctx* c, int B, hipStream_t s) {
-    const int NT = (c->k + 1) / 2, npairs = c->U4 / 2;
-    hipLaunchKernelGGL(lut_kernel, dim3((npairs * NT * 16 + 255) / 256), dim3(256), 0, s, c->Wt,
-                       reinterpret_cast<float2*>(c->lut), c->k, NT, npairs);
-    LAUNCH_CHECK();
     const int wsplit = c->n >= 8 ? 2 : 1;
     const dim3 grid(((B + 63) / 64) * wsplit, c->U4 / 2);
     const size_t sm = conv_pool_lds(c);

@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(
     __shared__ __attribute__((aligned(16))) float v2s[128];
     const int u = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rc = lane & 31, kk = lane >> 5;
+    STAMP(0);
     // stage the A fragments (prep2 wrote them in fragment order):
     // Af[(t*NKS+s)*64 + l] = A2[32t + (l&31)][2s + (l>>5)]
     {
@@ -60,6 +61,7 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(
         v2s[tid] = tid < FC_H ? V2[(size_t)u * FC_H + tid] : 0.f;
     }
     __syncthreads();
+    STAMP(1);
     const float a1 = alpha[u], s1 = shift[u];
     for (int it = 0; it < FC_BTW; ++it) {
         const int bt = (blockIdx.x * 4 + wave) * FC_BTW + it;
@@ -77,6 +79,7 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(
                        mix32(seed_hi + (uint32_t)u)) | 1u;
         const uint8_t* km = (MODE == 3) ? keep_mask + (size_t)min(b, B - 1) * FC_H * U + (size_t)u * FC_H
                                         : nullptr;
+        if (it == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(2); }
         float zp = 0.f;
         uint32_t words[FC_RT];
 #pragma unroll
@@ -114,6 +117,7 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(
             }
             words[t] = word;
         }
+        if (it == 0) STAMP(3);
         zp += __shfl_xor(zp, 32, 64);
 #pragma unroll
         for (int t = 0; t < FC_RT; ++t) words[t] |= __shfl_xor(words[t], 32, 64);
@@ -128,6 +132,7 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(
             }
         }
     }
+    STAMP(4);
 }
 
 int launch_fc_fwd(explainn_ctx* c, const explainn_params* p, int B, bool train,
@@ -208,12 +213,14 @@ __global__ __launch_bounds__(64) void passA_kernel(const float* __restrict__ ext
         rdz = live ? dzu[bc] : 0.f;
         rw = bu[bc];
     };
+    STAMP(0);
     if (bbeg < bend) fetch(bbeg);
     for (int b0 = bbeg; b0 < bend; b0 += 64) {
 #pragma unroll
         for (int i = 0; i < 32; ++i) tq[i * QT_LD + lane] = rq[i];
         tw[lane] = rw;
         tdz[lane] = rdz;
+        if (b0 == bbeg) STAMP(1);
         if (b0 + 64 < bend) fetch(b0 + 64);           // in flight during the MFMAs below
         const int ks = (min(bend - b0, 64) + 1) >> 1;
         for (int s = 0; s < ks; ++s) {
@@ -230,6 +237,7 @@ __global__ __launch_bounds__(64) void passA_kernel(const float* __restrict__ ext
             }
         }
     }
+    STAMP(2);
     // D[r][w]: lane holds column w = wt*32+rc, rows r = 32t + (g&3) + 8(g>>2) + 4kk
     const int w = wt * 32 + rc;
     if (w < NS) {
@@ -249,6 +257,7 @@ __global__ __launch_bounds__(64) void passA_kernel(const float* __restrict__ ext
             if (kk == 0 && r < FC_H) Sep[((size_t)u * ACH + ch) * FC_H + r] = sv;
         }
     }
+    STAMP(3);
 }
 
 int launch_passA(explainn_ctx* c, int B, hipStream_t s) {
@@ -279,6 +288,7 @@ __global__ __launch_bounds__(256) void passB_kernel(
     float* k0s = Mf + NWT * NKS * 64;                  // [NWT*32]
     const int u = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rc = lane & 31, kk = lane >> 5;
+    STAMP(0);
     // A fragments: Tf[(wt*RKS+s)*64+l] = T[r=2s+(l>>5)][w=wt*32+(l&31)],  Mf likewise over v
     for (int i = tid; i < NWT * RKS * 64; i += 256) {
         const int l = i & 63, s = (i >> 6) % RKS, wt = (i >> 6) / RKS;
@@ -292,6 +302,7 @@ __global__ __launch_bounds__(256) void passB_kernel(
     }
     for (int i = tid; i < NWT * 32; i += 256) k0s[i] = (i < NS) ? k0p[(size_t)u * NS + i] : 0.f;
     __syncthreads();
+    STAMP(1);
     const float a1 = alpha[u], s1 = shift[u];
     const float mu = (float)mug[u];
     const float isg = (float)(1.0 / sig1[u]);
@@ -310,6 +321,7 @@ __global__ __launch_bounds__(256) void passB_kernel(
         const float dzb = dz[(size_t)u * Bs + b];
         const uint32_t wds[4] = {wv.x, wv.y, wv.z, wv.w};
         float sA = 0.f, sB = 0.f;
+        if (it == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(2); }
 #pragma unroll
         for (int wt = 0; wt < NWT; ++wt) {
             f32x16 acc;
@@ -325,6 +337,7 @@ __global__ __launch_bounds__(256) void passB_kernel(
             }
 #pragma unroll
             for (int s = 0; s < NKS; ++s) acc = MFMA32(Mf[(wt * NKS + s) * 64 + lane], nqf[s], acc);
+            if (it == 0 && wt == 0) STAMP(3);
             // D[w][b]: lane holds its sequence b, rows w = wt*32 + (g&3) + 8(g>>2) + 4kk
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
@@ -339,6 +352,7 @@ __global__ __launch_bounds__(256) void passB_kernel(
                 }
             }
         }
+        if (it == 0) STAMP(4);
         sA = wave_sum(sA);
         sB = wave_sum(sB);
         if (lane == 0) {
@@ -346,6 +360,7 @@ __global__ __launch_bounds__(256) void passB_kernel(
             d[0] = sA; d[1] = sB;
         }
     }
+    STAMP(5);
 }
 
 template <int NQ>

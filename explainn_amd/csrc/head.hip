@@ -134,23 +134,38 @@ int launch_loss(explainn_ctx* c, int kind, const float* logits, const float* y, 
     return EXPLAINN_OK;
 }
 
+// d loss / d logit for one (sequence, task): either read from `dl`, or -- FUSED, used by
+// explainn_train_step when T is small -- recomputed from logits and targets so that the separate
+// loss launch (and its ~4 us floor) disappears; unit 0's block then also reduces the loss value.
+template <bool FUSED>
+__device__ __forceinline__ float dl_at(const float* __restrict__ dl, const float* __restrict__ logits,
+                                       const float* __restrict__ y, int kind, float invN, int i) {
+    if (!FUSED) return dl[i];
+    const float x = logits[i], t = y[i];
+    if (kind == EXPLAINN_LOSS_BCE_WITH_LOGITS) return (1.0f / (1.0f + expf(-x)) - t) * invN;
+    return 2.0f * (x - t) * invN;
+}
+
 // one block per unit: final-layer gradients, BN3 backward -> dz[u][b]
+template <bool FUSED>
 __global__ __launch_bounds__(256) void head_bwd_kernel(
-    const float* __restrict__ dl, const float* __restrict__ Wf, const float* __restrict__ g3,
-    const float* __restrict__ o, const float* __restrict__ zhat, const float* __restrict__ sig3,
-    float* __restrict__ dz, float* __restrict__ gWf, float* __restrict__ gbf,
-    float* __restrict__ gg3, float* __restrict__ gb3, float* __restrict__ gc2, int U, int T,
-    int Bs, int B) {
+    const float* __restrict__ dl, const float* __restrict__ logits, const float* __restrict__ y,
+    int kind, float* __restrict__ loss_out, const float* __restrict__ Wf,
+    const float* __restrict__ g3, const float* __restrict__ o, const float* __restrict__ zhat,
+    const float* __restrict__ sig3, float* __restrict__ dz, float* __restrict__ gWf,
+    float* __restrict__ gbf, float* __restrict__ gg3, float* __restrict__ gb3,
+    float* __restrict__ gc2, int U, int T, int Bs, int B) {
     __shared__ double red[4];
     const int u = blockIdx.x, tid = threadIdx.x;
     const float* ou = o + (size_t)u * Bs;
     const float* zh = zhat + (size_t)u * Bs;
     float* dzu = dz + (size_t)u * Bs;
+    const float invN = 1.0f / (float)(B * T);
     double s1 = 0, s2 = 0;
     for (int b = tid; b < B; b += 256) {
         float dob = 0.f;
-        const float* dr = dl + (size_t)b * T;
-        for (int t = 0; t < T; ++t) dob = fmaf(dr[t], Wf[(size_t)t * U + u], dob);
+        for (int t = 0; t < T; ++t)
+            dob = fmaf(dl_at<FUSED>(dl, logits, y, kind, invN, b * T + t), Wf[(size_t)t * U + u], dob);
         const float d3 = ou[b] > 0.f ? dob : 0.f;
         dzu[b] = d3;
         s1 += (double)d3;
@@ -164,23 +179,48 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
     if (tid == 0) { gg3[u] = (float)S2; gb3[u] = (float)S1; gc2[u] = 0.f; }
     for (int t = 0; t < T; ++t) {
         double a = 0;
-        for (int b = tid; b < B; b += 256) a = fma((double)dl[(size_t)b * T + t], (double)ou[b], a);
+        for (int b = tid; b < B; b += 256)
+            a = fma((double)dl_at<FUSED>(dl, logits, y, kind, invN, b * T + t), (double)ou[b], a);
         const double tot = block_sum_256(a, red);
         if (tid == 0) gWf[(size_t)t * U + u] = (float)tot;
         if (u == 0) {
             double c = 0;
-            for (int b = tid; b < B; b += 256) c += (double)dl[(size_t)b * T + t];
+            for (int b = tid; b < B; b += 256) c += (double)dl_at<FUSED>(dl, logits, y, kind, invN, b * T + t);
             const double ct = block_sum_256(c, red);
             if (tid == 0) gbf[t] = (float)ct;
         }
+    }
+    if (FUSED && u == 0) {
+        double acc = 0;
+        for (int i = tid; i < B * T; i += 256) {
+            const float x = logits[i], t = y[i];
+            float l;
+            if (kind == EXPLAINN_LOSS_BCE_WITH_LOGITS) l = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+            else { const float e = x - t; l = e * e; }
+            acc += (double)l;
+        }
+        const double tot = block_sum_256(acc, red);
+        if (tid == 0) *loss_out = (float)(tot / (double)(B * T));
     }
 }
 
 int launch_head_bwd(explainn_ctx* c, const explainn_params* p, const explainn_grads* g,
                     const float* dlogits, int B, hipStream_t s) {
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(c->U), dim3(256), 0, s, dlogits, p->final_w, p->bn3_w,
-                       c->o, c->zhat, c->sig3, c->dz, g->final_w, g->final_b, g->bn3_w, g->bn3_b,
-                       g->fc2_b, c->U, c->T, c->Bs, B);
+    hipLaunchKernelGGL(head_bwd_kernel<false>, dim3(c->U), dim3(256), 0, s, dlogits,
+                       (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr, p->final_w,
+                       p->bn3_w, c->o, c->zhat, c->sig3, c->dz, g->final_w, g->final_b, g->bn3_w,
+                       g->bn3_b, g->fc2_b, c->U, c->T, c->Bs, B);
+    LAUNCH_CHECK();
+    return EXPLAINN_OK;
+}
+
+// loss + its gradient folded into the head backward (explainn_train_step, small T)
+int launch_head_bwd_fused_loss(explainn_ctx* c, const explainn_params* p, const explainn_grads* g,
+                               int kind, const float* logits, const float* y, float* loss_out, int B,
+                               hipStream_t s) {
+    hipLaunchKernelGGL(head_bwd_kernel<true>, dim3(c->U), dim3(256), 0, s, (const float*)nullptr,
+                       logits, y, kind, loss_out, p->final_w, p->bn3_w, c->o, c->zhat, c->sig3, c->dz,
+                       g->final_w, g->final_b, g->bn3_w, g->bn3_b, g->fc2_b, c->U, c->T, c->Bs, B);
     LAUNCH_CHECK();
     return EXPLAINN_OK;
 }

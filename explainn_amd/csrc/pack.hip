@@ -2,8 +2,8 @@
 // (train.py:289, sequence/__init__.py:19-26) becomes base codes, and -- for train mode -- the
 // unit-independent input moments that give BatchNorm1 its batch statistics in closed form.
 //
-//   pack_onehot   x (B,4,L) fp32  ->  codesT [L][Bs] u8   (0..3, 4 = N / padding lanes)
-//   pack_bits     codesT -> pk2 [PW][Bs] (2 bit/base), nmask [NW][Bs] (1 bit/base)
+//   pack_onehot   x (B,4,L) fp32  ->  codesT [L][Bs] u8   (0..3, 4 = N / padding lanes),
+//                 pk2 [PW][Bs] (2 bit/base) and nmask [NW][Bs] (1 bit/base) from the same tile
 //   pair_counts   cnt[d][q][a*4+a'] = #{b : s[b,q]=a and s[b,q+d]=a'}           (exact, int)
 //   gram          G[(a,j),(a',j')] = (1/N) sum_{q=j}^{j+Lo-1} cnt[j'-j][q][a,a'],  m = diag(G)
 //
@@ -11,15 +11,18 @@
 #include "common.h"
 
 __global__ __launch_bounds__(256) void pack_onehot_kernel(const float* __restrict__ x,
-                                                          uint8_t* __restrict__ codesT, int B,
-                                                          int L, int Bs, int* __restrict__ flags) {
+                                                          uint8_t* __restrict__ codesT,
+                                                          uint32_t* __restrict__ pk2,
+                                                          uint32_t* __restrict__ nmask, int B,
+                                                          int L, int Bs, int PW, int NW,
+                                                          int* __restrict__ flags) {
     __shared__ uint8_t tile[64][68];
     const int b0 = blockIdx.x * 64, p0 = blockIdx.y * 64;
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     int bad = 0;
     for (int i = q; i < 64; i += 4) {
         const int b = b0 + i, p = p0 + lane;
-        uint8_t code = 4;
+        uint8_t code = (p < L) ? 4 : 0;             // N for padding lanes, 'A' past the sequence end
         if (b < B && p < L) {
             const float* xp = x + (size_t)b * 4 * L + p;
             const float v0 = xp[0], v1 = xp[L], v2 = xp[2 * (size_t)L], v3 = xp[3 * (size_t)L];
@@ -35,28 +38,25 @@ __global__ __launch_bounds__(256) void pack_onehot_kernel(const float* __restric
         const int p = p0 + pp;
         if (p < L) codesT[(size_t)p * Bs + b0 + lane] = tile[lane][pp];
     }
-    if (bad) atomicOr(flags, 1);
-}
-
-// one thread per (32-position word, sequence)
-__global__ __launch_bounds__(256) void pack_bits_kernel(const uint8_t* __restrict__ codesT,
-                                                        uint32_t* __restrict__ pk2,
-                                                        uint32_t* __restrict__ nmask, int L,
-                                                        int Bs, int PW, int NW) {
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    const int w = blockIdx.y;
-    if (b >= Bs) return;
-    uint32_t lo = 0, hi = 0, nm = 0;
+    // packed forms of the same tile: wave q packs positions [16q, 16q+16) into one 2-bit word per
+    // sequence; waves 0 and 1 also build the two 32-position N-mask words
+    {
+        uint32_t w2 = 0, nm = 0;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        const int p = w * 32 + i;
-        uint32_t c = (p < L) ? codesT[(size_t)p * Bs + b] : 0u;
-        if (c > 3u) { nm |= 1u << i; c = 0; }
-        if (i < 16) lo |= c << (2 * i); else hi |= c << (2 * (i - 16));
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t c = tile[lane][16 * q + i];
+            w2 |= (c > 3u ? 0u : c) << (2 * i);
+        }
+        const int wi = (p0 >> 4) + q;
+        if (wi < PW) pk2[(size_t)wi * Bs + b0 + lane] = w2;
+        if (q < 2) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) nm |= (tile[lane][32 * q + i] > 3u ? 1u : 0u) << i;
+            const int ni = (p0 >> 5) + q;
+            if (ni < NW) nmask[(size_t)ni * Bs + b0 + lane] = nm;
+        }
     }
-    if (w < NW) nmask[(size_t)w * Bs + b] = nm;
-    if (2 * w < PW) pk2[(size_t)(2 * w) * Bs + b] = lo;
-    if (2 * w + 1 < PW) pk2[(size_t)(2 * w + 1) * Bs + b] = hi;
+    if (bad) atomicOr(flags, 1);
 }
 
 // one wavefront per (gap d, position q); lanes stride over the batch, the 16 pair bins are
@@ -116,15 +116,10 @@ __global__ __launch_bounds__(256) void gram_kernel(const int* __restrict__ cnt,
 
 int launch_pack(explainn_ctx* c, const float* x, int B, bool counts, hipStream_t s) {
     const int gb = (B + 63) / 64;
-    hipLaunchKernelGGL(pack_onehot_kernel, dim3(gb, (c->L + 63) / 64), dim3(256), 0, s, x,
-                       c->codesT, B, c->L, c->Bs, c->flags);
+    // position tiles cover the padded tail too, so the packed words past L are written (as zeros)
+    hipLaunchKernelGGL(pack_onehot_kernel, dim3(gb, (c->NW * 32 + 63) / 64), dim3(256), 0, s, x,
+                       c->codesT, c->pk2, c->nmask, B, c->L, c->Bs, c->PW, c->NW, c->flags);
     LAUNCH_CHECK();
-    {
-        const int bp = gb * 64;
-        hipLaunchKernelGGL(pack_bits_kernel, dim3((bp + 255) / 256, c->NW), dim3(256),
-                           0, s, c->codesT, c->pk2, c->nmask, c->L, c->Bs, c->PW, c->NW);
-        LAUNCH_CHECK();
-    }
     if (counts) {
         const int waves = c->k * c->L;
         hipLaunchKernelGGL(pair_counts_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, c->codesT,

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(128) void prep1_kernel(
     float* __restrict__ rv, int64_t* nbt, const double* __restrict__ G,
     const double* __restrict__ m, float* __restrict__ alpha, float* __restrict__ shift,
     double* __restrict__ mug, double* __restrict__ sig1, double* __restrict__ Gw,
-    float* __restrict__ Wt, int U, int k, int B, int Lo) {
+    float* __restrict__ Wt, float* __restrict__ lut, int U, int k, int B, int Lo) {
     __shared__ double wsh[4 * MAX_K];
     __shared__ double red[2];
     const int u = blockIdx.x, tid = threadIdx.x, K4 = 4 * k;
@@ -38,6 +38,20 @@ __global__ __launch_bounds__(128) void prep1_kernel(
         wsh[i] = (double)wv;
     }
     for (int j = tid; j < k; j += 128) Wt[((size_t)(u >> 2) * k + j) * 20 + 16 + (u & 3)] = 0.f;
+    __syncthreads();
+    // dinucleotide tables for conv_pool: lut[pair][t][c0 c1].{x,y} = W[u][c0][2t] + W[u][c1][2t+1]
+    {
+        const int NT = (k + 1) / 2;
+        for (int e = tid; e < NT * 16; e += 128) {
+            const int t = e >> 4, code4 = e & 15;
+            float sum = 0.f;
+            for (int i = 0; i < 2; ++i) {
+                const int j = 2 * t + i;
+                if (j < k) sum += (float)wsh[((code4 >> (2 * i)) & 3) * k + j];
+            }
+            lut[(((size_t)(u >> 1) * NT + t) * 16 + code4) * 2 + (u & 1)] = sum;
+        }
+    }
     if (u >= U) {
         if (tid == 0) { alpha[u] = 0.f; shift[u] = 0.f; }
         return;
@@ -82,11 +96,11 @@ int launch_prep1(explainn_ctx* c, const explainn_params* p, int B, bool train, h
     if (train)
         hipLaunchKernelGGL(prep1_kernel<true>, dim3(c->U4), dim3(128), 0, s, p->conv_w, p->conv_b,
                            p->bn1_w, p->bn1_b, p->bn1_rm, p->bn1_rv, p->bn1_nbt, c->G, c->m,
-                           c->alpha, c->shift, c->mug, c->sig1, c->Gw, c->Wt, c->U, c->k, B, c->Lo);
+                           c->alpha, c->shift, c->mug, c->sig1, c->Gw, c->Wt, c->lut, c->U, c->k, B, c->Lo);
     else
         hipLaunchKernelGGL(prep1_kernel<false>, dim3(c->U4), dim3(128), 0, s, p->conv_w, p->conv_b,
                            p->bn1_w, p->bn1_b, p->bn1_rm, p->bn1_rv, (int64_t*)nullptr, c->G, c->m,
-                           c->alpha, c->shift, c->mug, c->sig1, c->Gw, c->Wt, c->U, c->k, B, c->Lo);
+                           c->alpha, c->shift, c->mug, c->sig1, c->Gw, c->Wt, c->lut, c->U, c->k, B, c->Lo);
     LAUNCH_CHECK();
     return EXPLAINN_OK;
 }
@@ -143,10 +157,12 @@ __global__ __launch_bounds__(64) void qmom_kernel(
             }
         }
     };
+    STAMP(0);
     if (bbeg < bend) fetch(bbeg);
     for (int b0 = bbeg; b0 < bend; b0 += 64) {
 #pragma unroll
         for (int i = 0; i < 32; ++i) tA[i * QT_LD + lane] = ra[i];
+        if (b0 == bbeg) STAMP(1);
         if (NWT > 1 && !same) {
 #pragma unroll
             for (int i = 0; i < (NWT > 1 ? 32 : 1); ++i) tB[i * QT_LD + lane] = rb[i];
@@ -163,6 +179,7 @@ __global__ __launch_bounds__(64) void qmom_kernel(
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc, 0, 0, 0);
         }
     }
+    STAMP(2);
     if (wB < NS) {
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
@@ -174,6 +191,7 @@ __global__ __launch_bounds__(64) void qmom_kernel(
         s1 += __shfl_xor(s1, 32, 64);
         if (kk == 0 && wB < NS) S1p[((size_t)u * QCH + ch) * NS + wB] = s1;
     }
+    STAMP(3);
 }
 
 int launch_qmoments(explainn_ctx* c, int B, hipStream_t s) {

@@ -246,3 +246,30 @@ def test_builtin_dropout_rate_and_scaling():
     with torch.no_grad():
         a2 = m(x)
     assert torch.equal(a, a2), "same torch seed -> same mask"
+
+
+@pytest.mark.parametrize("T,kind", [(1, "binary"), (3, "linear"), (6, "binary")])
+def test_step_engine_vs_oracle(T, kind):
+    """explainn_train_step (what bench.py times): loss value, logits and the flat gradient buffer
+    against the oracle; T <= 4 takes the loss-fused head backward, T > 4 the separate loss kernel."""
+    from explainn_amd.engine import StepEngine
+    U, k, L, B = 6, 19, 200, 100
+    sd = orc.random_state_dict(U, k, L, T, seed=11)
+    x = orc.random_onehot(B, L, seed=12, n_frac=0.01)
+    rng = np.random.default_rng(13)
+    y = ((rng.random((B, T)) > 0.5) if kind == "binary" else rng.standard_normal((B, T))).astype(np.float32)
+    m = _model(sd, U, k, L, T).train()
+    m.dropout_p = 0.0
+    eng = StepEngine(m, B, loss=kind)
+    logits, loss = eng.step(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda())
+    torch.cuda.synchronize()
+    ref_logits, cache, _ = orc.forward(sd, x, training=True, return_cache=True)
+    ref_loss, dl = (orc.bce_with_logits if kind == "binary" else orc.mse)(ref_logits, y)
+    ref_grads = orc.backward(cache, dl)
+    _close(_np(logits), ref_logits, what="logits")
+    _close(loss.item(), ref_loss, tol=1e-5, what="loss")
+    for (key, _), v in zip(m.named_parameters(), eng.views):
+        if key in ZERO_GRAD:
+            assert np.abs(_np(v)).max() < 1e-6, key
+        else:
+            _close(_np(v).reshape(ref_grads[key].shape), ref_grads[key], tol=2e-4, what="grad " + key)

@@ -1,0 +1,71 @@
+// In-kernel stamp harness: compiles the REAL kernels of explainn_amd/csrc with EXPLAINN_STAMP and
+// prints, per kernel, the median shader cycles each wave spends in each phase (C2 shapes).
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/stampbench.hip -o gpurun_out/stampbench
+#define EXPLAINN_STAMP 1
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <stdarg.h>
+#include <algorithm>
+#include <vector>
+__device__ unsigned long long g_stamps[1 << 20];
+void explainn_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vprintf(fmt, ap); va_end(ap); printf("\n"); }
+#include "../explainn_amd/csrc/prep.hip"
+#include "../explainn_amd/csrc/fc.hip"
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+static void report(const char* name, int waves, int nst, float ms) {
+    std::vector<unsigned long long> h((size_t)waves * 8);
+    CK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_stamps), h.size() * 8));
+    printf("%-10s event %.1f us | median cycles per phase:", name, ms * 1e3);
+    for (int p = 1; p < nst; ++p) {
+        std::vector<double> d;
+        for (int w = 0; w < waves; ++w) if (h[w * 8 + p] && h[w * 8 + p - 1]) d.push_back((double)(h[w * 8 + p] - h[w * 8 + p - 1]));
+        std::sort(d.begin(), d.end());
+        printf("  [%d->%d] %.0f (p90 %.0f)", p - 1, p, d.empty() ? -1.0 : d[d.size() / 2], d.empty() ? -1.0 : d[d.size() * 9 / 10]);
+    }
+    std::vector<double> tot;
+    for (int w = 0; w < waves; ++w) tot.push_back((double)(h[w * 8 + nst - 1] - h[w * 8]));
+    std::sort(tot.begin(), tot.end());
+    printf("  | total p50 %.0f max %.0f\n", tot[tot.size() / 2], tot.back());
+}
+
+int main() {
+    const int U = 300, n = 26, B = 1024, Bs = 1088, NQ = 26, NS = ns_stride(NQ), NKS = 13, QCH = 8, ACH = 8;
+    auto dalloc = [](size_t bytes) { void* p; CK(hipMalloc(&p, bytes)); CK(hipMemset(p, 0, bytes)); return p; };
+    float* ext = (float*)dalloc((size_t)U * n * Bs * 4); float* alpha = (float*)dalloc(U * 4); float* shift = (float*)dalloc(U * 4);
+    std::vector<float> he((size_t)U * n * Bs); for (auto& v : he) v = (rand() % 2000) * 1e-3f - 1.f;
+    CK(hipMemcpy(ext, he.data(), he.size() * 4, hipMemcpyHostToDevice));
+    std::vector<float> ha(U, 0.7f); CK(hipMemcpy(alpha, ha.data(), U * 4, hipMemcpyHostToDevice));
+    float* qs0 = (float*)dalloc(U * NS * 4); float* S1p = (float*)dalloc((size_t)U * QCH * NS * 4); float* S2p = (float*)dalloc((size_t)U * QCH * NS * NS * 4);
+    float* A2f = (float*)dalloc((size_t)U * 4 * NKS * 64 * 4); float* sh2 = (float*)dalloc(U * 100 * 4); float* V2 = (float*)dalloc(U * 100 * 4);
+    std::vector<float> hw((size_t)U * 4 * NKS * 64); for (auto& v : hw) v = (rand() % 2000) * 1e-3f - 1.f;
+    CK(hipMemcpy(A2f, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+    uint4* bits = (uint4*)dalloc((size_t)U * Bs * 16 + 64); float* z = (float*)dalloc((size_t)U * Bs * 4); float* o = (float*)dalloc((size_t)U * Bs * 4);
+    float* dz = (float*)dalloc((size_t)U * Bs * 4 + 64); float* EQp = (float*)dalloc((size_t)U * ACH * 100 * NS * 4); float* Sep = (float*)dalloc((size_t)U * ACH * 100 * 4);
+    float* Tt = (float*)dalloc((size_t)(U * 100 + 2) * NS * 4); float* M = (float*)dalloc((size_t)(U * NS + 2) * NS * 4); float* k0p = (float*)dalloc(U * NS * 4);
+    double* mug = (double*)dalloc(U * 8); double* sig1 = (double*)dalloc(U * 8); std::vector<double> one(U, 1.0); CK(hipMemcpy(sig1, one.data(), U * 8, hipMemcpyHostToDevice));
+    float* dy = (float*)dalloc((size_t)U * n * Bs * 4); float* S12p = (float*)dalloc((size_t)U * (Bs / 32) * 2 * 4);
+    float* fz = (float*)dalloc(U * 4);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); float ms;
+    for (int rep = 0; rep < 2; ++rep) {
+        CK(hipMemset(fz, 0, 4));
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(qmom_kernel<26>, dim3(QCH, U, 1), dim3(64), 0, 0, ext, alpha, shift, qs0, S1p, S2p, n, Bs, B, QCH);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep) report("qmom", QCH * U, 4, ms);
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((fc_fwd_kernel<26, 2>), dim3(4, U), dim3(256), 0, 0, ext, alpha, shift, A2f, sh2, V2, bits, z, (const uint8_t*)nullptr, 19661u, 1.4285715f, 1u, 2u, fz, fz, fz, fz, fz, o, n, Bs, B, U);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep) report("fc_fwd", 4 * U * 4, 5, ms);
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(passA_kernel<26>, dim3(ACH, U, 1), dim3(64), 0, 0, ext, alpha, shift, dz, bits, EQp, Sep, n, Bs, B, ACH);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep) report("passA", ACH * U, 4, ms);
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(passB_kernel<26>, dim3(4, U), dim3(256), passB_lds<26>(), 0, ext, alpha, shift, dz, bits, Tt, M, k0p, mug, sig1, dy, S12p, n, Bs, B);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep) report("passB", 4 * U * 4, 6, ms);
+    }
+    return 0;
+}
