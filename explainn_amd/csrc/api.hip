@@ -70,6 +70,8 @@ void carve(explainn_ctx* c, Carver& cv) {
     cv.take(&c->md2h, U * FC_H);
     cv.take(&c->Tt, (U * FC_H + 2) * NS);
     cv.take(&c->M, (U * NS + 2) * NS);
+    cv.take(&c->Ttf, U * ((c->NQ + 31) / 32) * (FC_H / 2) * 64);
+    cv.take(&c->Mff, U * ((c->NQ + 31) / 32) * ((c->NQ + 1) / 2) * 64);
     cv.take(&c->k0p, U * NS);
     cv.take(&c->dy, U4 * n * Bs);
     cv.take(&c->S12p, U * (Bs / 32) * 2);

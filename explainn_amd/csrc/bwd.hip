@@ -50,14 +50,16 @@ __global__ __launch_bounds__(256) void mid2a_kernel(
     const float* __restrict__ EQs, const float* __restrict__ A2, const float* __restrict__ sig2,
     const float* __restrict__ fc1_w, const float* __restrict__ fc2_w, const float* __restrict__ g2,
     const double* __restrict__ qbar, const float* __restrict__ C, const float* __restrict__ md2,
-    const float* __restrict__ md2h, float* __restrict__ Tt, float* __restrict__ g_fc1_w, int n,
-    int NS, int B, float scale) {
+    const float* __restrict__ md2h, float* __restrict__ Tt, float* __restrict__ Ttf,
+    float* __restrict__ g_fc1_w, int n, int NS, int NWT, int B, float scale) {
     const int u = blockIdx.x;
     const float* Cu = C + (size_t)u * NS * NS;
     for (int e = threadIdx.x; e < FC_H * NS; e += 256) {
         const int r = e / NS, w = e % NS, ch = u * FC_H + r;
         const double sv = (double)scale * (double)fc2_w[ch];
-        Tt[(size_t)ch * NS + w] = (float)(sv * (double)A2[(size_t)ch * NS + w]);
+        const float tval = (float)(sv * (double)A2[(size_t)ch * NS + w]);
+        Tt[(size_t)ch * NS + w] = tval;
+        Ttf[(size_t)u * NWT * (FC_H / 2) * 64 + ((size_t)(w >> 5) * (FC_H / 2) + (r >> 1)) * 64 + (r & 1) * 32 + (w & 31)] = tval;
         if (w < n) {
             const float* v1 = fc1_w + (size_t)ch * n;
             double hq = 0;
@@ -76,7 +78,8 @@ __global__ __launch_bounds__(256) void mid2a_kernel(
 __global__ __launch_bounds__(256) void mid2b_kernel(
     const float* __restrict__ A2, const float* __restrict__ sig2, const float* __restrict__ fc1_w,
     const double* __restrict__ qbar, const float* __restrict__ md2, const float* __restrict__ md2h,
-    float* __restrict__ M, float* __restrict__ k0p, int n, int NS) {
+    float* __restrict__ M, float* __restrict__ Mff, float* __restrict__ k0p, int n, int NS, int NWT,
+    int NKS) {
     extern __shared__ float Msm[];            // [n][n]
     const int u = blockIdx.x;
     for (int e = threadIdx.x; e < NS * NS; e += 256) {
@@ -91,6 +94,8 @@ __global__ __launch_bounds__(256) void mid2b_kernel(
             Msm[v * n + w] = (float)acc;
         }
         M[(size_t)u * NS * NS + e] = (float)acc;
+        if ((v >> 1) < NKS)
+            Mff[(size_t)u * NWT * NKS * 64 + ((size_t)(w >> 5) * NKS + (v >> 1)) * 64 + (v & 1) * 32 + (w & 31)] = (float)acc;
     }
     __syncthreads();
     for (int w = threadIdx.x; w < NS; w += 256) {
@@ -113,10 +118,10 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
     const float* __restrict__ EQp, const float* __restrict__ Sep, const float* __restrict__ A2,
     const float* __restrict__ sh2, const float* __restrict__ sig2, const float* __restrict__ fc1_w,
     const float* __restrict__ fc2_w, const float* __restrict__ g2, const double* __restrict__ qbar,
-    const float* __restrict__ C, float* __restrict__ Tt, float* __restrict__ M,
-    float* __restrict__ k0p, float* __restrict__ g_fc2_w, float* __restrict__ g_bn2_w,
+    const float* __restrict__ C, float* __restrict__ Tt, float* __restrict__ Ttf,
+    float* __restrict__ M, float* __restrict__ Mff, float* __restrict__ k0p, float* __restrict__ g_fc2_w, float* __restrict__ g_bn2_w,
     float* __restrict__ g_bn2_b, float* __restrict__ g_fc1_b, float* __restrict__ g_fc1_w, int n,
-    int NS, int B, int ACH, float scale) {
+    int NS, int NWT, int NKS, int B, int ACH, float scale) {
     extern __shared__ float fsm[];
     const int ld = n + 1;
     float* V1s = fsm;                        // [100][ld]
@@ -130,13 +135,21 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
     float* cfs = md2s + FC_H;                // [100]  md2h / sig2
     float* md2hs = cfs + FC_H;               // [100]
     const int u = blockIdx.x, tid = threadIdx.x;
+    STAMP(0);
     for (int e = tid; e < FC_H * n; e += 1024) {
         const int r = e / n, w = e % n;
         const size_t ch = (size_t)u * FC_H + r;
         V1s[r * ld + w] = fc1_w[ch * n + w];
         A2s[r * ld + w] = A2[ch * NS + w];
         double eq = 0;
-        for (int c = 0; c < ACH; ++c) eq += (double)EQp[(((size_t)u * ACH + c) * FC_H + r) * NS + w];
+        for (int c0 = 0; c0 < ACH; c0 += 8) {         // eight partials in flight, fixed-order sum
+            float pv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                pv[i] = (c0 + i < ACH) ? EQp[(((size_t)u * ACH + c0 + i) * FC_H + r) * NS + w] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) eq += (double)pv[i];
+        }
         EQl[r * ld + w] = (float)eq;
     }
     for (int e = tid; e < n * n; e += 1024) Cs[e] = C[(size_t)u * NS * NS + (size_t)(e / n) * NS + (e % n)];
@@ -147,6 +160,7 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
         se[r] = (float)s;
     }
     __syncthreads();
+    STAMP(1);
     const double sc = (double)scale;
     if (tid < FC_H) {
         const int r = tid;
@@ -169,6 +183,7 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
         cfs[r] = (float)((dg2 / (double)B) / sg);
     }
     __syncthreads();
+    STAMP(2);
     for (int e = tid; e < NS * NS; e += 1024) {
         const int v = e / NS, w = e % NS;
         float acc = 0.f;
@@ -180,7 +195,10 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
             Ms[v * n + w] = acc;
         }
         M[(size_t)u * NS * NS + e] = acc;
+        if ((v >> 1) < NKS)
+            Mff[(size_t)u * NWT * NKS * 64 + ((size_t)(w >> 5) * NKS + (v >> 1)) * 64 + (v & 1) * 32 + (w & 31)] = acc;
     }
+    STAMP(3);
     for (int e = tid; e < FC_H * NS; e += 1024) {
         const int r = e / NS, w = e % NS;
         const size_t ch = (size_t)u * FC_H + r;
@@ -199,8 +217,10 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
             g_fc1_w[ch * n + w] = (float)val;
         }
         Tt[ch * NS + w] = tv;
+        Ttf[(size_t)u * NWT * (FC_H / 2) * 64 + ((size_t)(w >> 5) * (FC_H / 2) + (r >> 1)) * 64 + (r & 1) * 32 + (w & 31)] = tv;
     }
     __syncthreads();
+    STAMP(4);
     for (int w = tid; w < NS; w += 1024) {
         double k0 = 0;
         if (w < n) {
@@ -209,6 +229,7 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
         }
         k0p[(size_t)u * NS + w] = (float)k0;
     }
+    STAMP(5);
 }
 
 static size_t mid_fused_lds(int n) {
@@ -220,8 +241,9 @@ int launch_mid_bwd(explainn_ctx* c, const explainn_params* p, const explainn_gra
     if (c->n <= 72) {
         hipLaunchKernelGGL(mid_fused_kernel, dim3(c->U), dim3(1024), mid_fused_lds(c->n), s, c->EQp,
                            c->Sep, c->A2, c->sh2, c->sig2, p->fc1_w, p->fc2_w, p->bn2_w, c->qbar,
-                           c->C, c->Tt, c->M, c->k0p, g->fc2_w, g->bn2_w, g->bn2_b, g->fc1_b,
-                           g->fc1_w, c->n, c->NS, B, c->ACH, c->fwd_scale);
+                           c->C, c->Tt, c->Ttf, c->M, c->Mff, c->k0p, g->fc2_w, g->bn2_w, g->bn2_b,
+                           g->fc1_b, g->fc1_w, c->n, c->NS, (c->NQ + 31) / 32, (c->NQ + 1) / 2, B, c->ACH,
+                           c->fwd_scale);
         LAUNCH_CHECK();
         return EXPLAINN_OK;
     }
@@ -230,12 +252,12 @@ int launch_mid_bwd(explainn_ctx* c, const explainn_params* p, const explainn_gra
                        g->bn2_w, g->bn2_b, g->fc1_b, c->n, c->NS, B, c->ACH, c->fwd_scale);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(mid2a_kernel, dim3(c->U), dim3(256), 0, s, c->EQs, c->A2, c->sig2, p->fc1_w,
-                       p->fc2_w, p->bn2_w, c->qbar, c->C, c->md2, c->md2h, c->Tt, g->fc1_w, c->n,
-                       c->NS, B, c->fwd_scale);
+                       p->fc2_w, p->bn2_w, c->qbar, c->C, c->md2, c->md2h, c->Tt, c->Ttf, g->fc1_w, c->n,
+                       c->NS, (c->NQ + 31) / 32, B, c->fwd_scale);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(mid2b_kernel, dim3(c->U), dim3(256), (size_t)c->n * c->n * sizeof(float), s,
-                       c->A2, c->sig2, p->fc1_w, c->qbar, c->md2, c->md2h, c->M, c->k0p, c->n,
-                       c->NS);
+                       c->A2, c->sig2, p->fc1_w, c->qbar, c->md2, c->md2h, c->M, c->Mff, c->k0p, c->n,
+                       c->NS, (c->NQ + 31) / 32, (c->NQ + 1) / 2);
     LAUNCH_CHECK();
     return EXPLAINN_OK;
 }
@@ -258,8 +280,11 @@ __global__ __launch_bounds__(64) void conv_bwd_kernel(const float* __restrict__ 
     uint32_t* nms = smem + (size_t)PW * 64;
     const int lane = threadIdx.x, tile = blockIdx.x, u = blockIdx.y;
     const int b = tile * 64 + lane;
-    for (int w = 0; w < PW; ++w) pks[w * 64 + lane] = pk2[(size_t)w * Bs + b];
-    for (int w = 0; w < NW; ++w) nms[w * 64 + lane] = nmask[(size_t)w * Bs + b];
+    STAMP(0);
+    stage_column(pks + lane, pk2 + b, PW, Bs);
+    stage_column(nms + lane, nmask + b, NW, Bs);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(1);
     constexpr uint32_t KMASK = (K >= 32) ? 0xffffffffu : ((1u << K) - 1u);
     float a1[K], a2[K], a3[K], an[K];
 #pragma unroll
@@ -300,14 +325,27 @@ __global__ __launch_bounds__(64) void conv_bwd_kernel(const float* __restrict__ 
             }
         }
     }
-    // sums over the 64 lanes; output index (a,j) -> a*K + j
-    float* out = Dspp + ((size_t)u * (Bs / 64) + tile) * 4 * K;
+    STAMP(2);
+    // sums over the 64 lanes through LDS: every lane parks its 4K values as a column of a
+    // [4K][65] tile, then lane t adds up row t (conflict-free both ways); output (a,j) -> a*K + j
+    float* red = reinterpret_cast<float*>(smem);      // the code tiles are dead by now
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-        const float s0 = wave_sum(tot - an[j] - a1[j] - a2[j] - a3[j]);
-        const float s1 = wave_sum(a1[j]), s2 = wave_sum(a2[j]), s3 = wave_sum(a3[j]);
-        if (lane == 0) { out[j] = s0; out[K + j] = s1; out[2 * K + j] = s2; out[3 * K + j] = s3; }
+        red[(j) * 65 + lane] = tot - an[j] - a1[j] - a2[j] - a3[j];
+        red[(K + j) * 65 + lane] = a1[j];
+        red[(2 * K + j) * 65 + lane] = a2[j];
+        red[(3 * K + j) * 65 + lane] = a3[j];
     }
+    __syncthreads();
+    float* out = Dspp + ((size_t)u * (Bs / 64) + tile) * 4 * K;
+    for (int t = lane; t < 4 * K; t += 64) {
+        float sacc = 0.f;
+#pragma unroll 16
+        for (int l = 0; l < 64; ++l) sacc += red[t * 65 + l];
+        out[t] = sacc;
+    }
+    STAMP(3);
 }
 
 #define KB_DISPATCH(Kv, CALL)                                                                  \
@@ -329,7 +367,9 @@ __global__ __launch_bounds__(64) void conv_bwd_kernel(const float* __restrict__ 
 
 int launch_conv_bwd(explainn_ctx* c, int B, hipStream_t s) {
     const dim3 grid((B + 63) / 64, c->U);
-    const size_t sm = (size_t)(c->PW + c->NW) * 64 * sizeof(uint32_t);
+    size_t sm = (size_t)(c->PW + c->NW) * 64 * sizeof(uint32_t);
+    const size_t red_bytes = (size_t)4 * c->k * 65 * sizeof(float);
+    if (sm < red_bytes) sm = red_bytes;
 #define CALL(KK)                                                                               \
     hipLaunchKernelGGL(conv_bwd_kernel<KK>, grid, dim3(64), sm, s, c->dy, c->idx, c->pk2, c->nmask, \
                        c->Dspp, c->U, c->n, c->Bs, c->PW, c->NW)

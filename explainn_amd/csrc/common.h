@@ -69,6 +69,8 @@ struct explainn_ctx {
     float* md2;           // [U][100]
     float* md2h;          // [U][100]
     float* Tt;            // [U][100][NS]
+    float* Ttf;           // [U][NWT][50][64]  T in MFMA A-fragment order (passB copies it to LDS)
+    float* Mff;           // [U][NWT][NKS][64] M in MFMA A-fragment order
     float* M;             // [U][NS][NS]
     float* k0p;           // [U][NS]
     float* dy;            // [U4][n][Bs]
@@ -136,6 +138,21 @@ extern __device__ unsigned long long g_stamps[];
 #else
 #define STAMP(i) do { } while (0)
 #endif
+
+// Copy `rows` rows of a [rows][Bs] u32 array (this lane's column b) into an LDS tile [rows][64].
+// Loads are issued eight at a time before any store: a plain `for (w) tile[w] = src[w]` with a
+// runtime trip count compiles to one exposed memory round trip per row (7-8 us for 27 rows).
+__device__ __forceinline__ void stage_column(uint32_t* __restrict__ tile_lane,
+                                             const uint32_t* __restrict__ src_b, int rows, int Bs) {
+    for (int w0 = 0; w0 < rows; w0 += 8) {
+        uint32_t t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = (w0 + i < rows) ? src_b[(size_t)(w0 + i) * Bs] : 0u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (w0 + i < rows) tile_lane[(w0 + i) * 64] = t[i];
+    }
+}
 
 // q = exp(alpha*ext + shift): every consumer must evaluate it identically
 __device__ __forceinline__ float qval(float alpha, float ext, float shift) {

@@ -55,6 +55,7 @@ __global__ __launch_bounds__(64) void conv_pool_kernel(const uint32_t* __restric
     const int wper = (n + wsplit - 1) / wsplit;
     const int wbeg = (blockIdx.x % wsplit) * wper, wend = min(n, wbeg + wper);
     const int quad = pair >> 1, off = (pair & 1) * 2;
+    STAMP(0);
     {
         const float2* src = lut + (size_t)pair * NT * 16;
         for (int i = lane; i < NT * 16; i += 64) L2[i] = src[i];
@@ -62,12 +63,13 @@ __global__ __launch_bounds__(64) void conv_pool_kernel(const uint32_t* __restric
             const float* w = Wt + ((size_t)quad * K + i / 5) * 20 + (i % 5) * 4 + off;
             Wp[i] = make_float2(w[0], w[1]);
         }
-        for (int w = 0; w < PW; ++w) pks[w * 64 + lane] = pk2[(size_t)w * Bs + b];
-        for (int w = 0; w < NW; ++w) nms[w * 64 + lane] = nmask[(size_t)w * Bs + b];
+        stage_column(pks + lane, pk2 + b, PW, Bs);
+        stage_column(nms + lane, nmask + b, NW, Bs);
     }
     const float sg0 = alpha[pair * 2] >= 0.f ? 1.f : -1.f;
     const float sg1 = alpha[pair * 2 + 1] >= 0.f ? 1.f : -1.f;
     __syncthreads();
+    STAMP(1);
     const char* Lb = reinterpret_cast<const char*>(L2);
     const char* Wb = reinterpret_cast<const char*>(Wp);
     const uint32_t* pl = pks + lane;
@@ -136,6 +138,7 @@ __global__ __launch_bounds__(64) void conv_pool_kernel(const uint32_t* __restric
         ext[o0] = sg0 * best0; idx[o0] = (uint8_t)bi0;
         ext[o1] = sg1 * best1; idx[o1] = (uint8_t)bi1;
     }
+    STAMP(2);
 }
 
 #define K_DISPATCH(Kv, CALL)                                                                   \

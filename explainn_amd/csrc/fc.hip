@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(
     float* __restrict__ oout, int n, int Bs, int B, int U) {
     constexpr int NS = ns_stride(NQ), NKS = (NQ + 1) / 2;
     constexpr bool TRAIN = MODE != 0;
-    __shared__ float Af[FC_RT * NKS * 64];
+    __shared__ __attribute__((aligned(16))) float Af[FC_RT * NKS * 64];
     __shared__ __attribute__((aligned(16))) float sh2s[128];
     __shared__ __attribute__((aligned(16))) float v2s[128];
     const int u = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -53,8 +53,16 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(
     // stage the A fragments (prep2 wrote them in fragment order):
     // Af[(t*NKS+s)*64 + l] = A2[32t + (l&31)][2s + (l>>5)]
     {
-        const float* src = A2f + (size_t)u * FC_RT * NKS * 64;
-        for (int i = tid; i < FC_RT * NKS * 64; i += 256) Af[i] = src[i];
+        const float4* src = reinterpret_cast<const float4*>(A2f + (size_t)u * FC_RT * NKS * 64);
+        float4* dst = reinterpret_cast<float4*>(Af);
+        constexpr int N4 = FC_RT * NKS * 16;          // float4 count, all loads issued before stores
+        float4 tv[(N4 + 255) / 256];
+#pragma unroll
+        for (int i = 0; i < (N4 + 255) / 256; ++i)
+            tv[i] = (tid + i * 256 < N4) ? src[tid + i * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < (N4 + 255) / 256; ++i)
+            if (tid + i * 256 < N4) dst[tid + i * 256] = tv[i];
     }
     if (tid < 128) {
         sh2s[tid] = tid < FC_H ? sh2[(size_t)u * FC_H + tid] : 0.f;
@@ -278,7 +286,7 @@ template <int NQ>
 __global__ __launch_bounds__(256) void passB_kernel(
     const float* __restrict__ ext, const float* __restrict__ alpha,
     const float* __restrict__ shift, const float* __restrict__ dz, const uint4* __restrict__ bits,
-    const float* __restrict__ Tt, const float* __restrict__ M, const float* __restrict__ k0p,
+    const float* __restrict__ Ttf, const float* __restrict__ Mff, const float* __restrict__ k0p,
     const double* __restrict__ mug, const double* __restrict__ sig1, float* __restrict__ dy,
     float* __restrict__ S12p, int n, int Bs, int B) {
     constexpr int NS = ns_stride(NQ), NKS = (NQ + 1) / 2, NWT = (NQ + 31) / 32, RKS = FC_H / 2;
@@ -289,16 +297,22 @@ __global__ __launch_bounds__(256) void passB_kernel(
     const int u = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rc = lane & 31, kk = lane >> 5;
     STAMP(0);
-    // A fragments: Tf[(wt*RKS+s)*64+l] = T[r=2s+(l>>5)][w=wt*32+(l&31)],  Mf likewise over v
-    for (int i = tid; i < NWT * RKS * 64; i += 256) {
-        const int l = i & 63, s = (i >> 6) % RKS, wt = (i >> 6) / RKS;
-        const int r = 2 * s + (l >> 5), w = wt * 32 + (l & 31);
-        Tf[i] = (w < NS) ? Tt[((size_t)u * FC_H + r) * NS + w] : 0.f;
-    }
-    for (int i = tid; i < NWT * NKS * 64; i += 256) {
-        const int l = i & 63, s = (i >> 6) % NKS, wt = (i >> 6) / NKS;
-        const int v = 2 * s + (l >> 5), w = wt * 32 + (l & 31);
-        Mf[i] = (w < NS && v < NS) ? M[((size_t)u * NS + v) * NS + w] : 0.f;
+    // A fragments Tf[(wt*RKS+s)*64+l] = T[r=2s+(l>>5)][w=wt*32+(l&31)] and Mf likewise over v are
+    // laid out by the mid kernels (Ttf/Mff); copy them with float4, all loads before the stores
+    {
+        constexpr int NT4 = NWT * RKS * 16, NM4 = NWT * NKS * 16, N4 = NT4 + NM4;
+        const float4* srcT = reinterpret_cast<const float4*>(Ttf + (size_t)u * NWT * RKS * 64);
+        const float4* srcM = reinterpret_cast<const float4*>(Mff + (size_t)u * NWT * NKS * 64);
+        float4* dst = reinterpret_cast<float4*>(Tf);  // Mf follows Tf contiguously
+        float4 tv[(N4 + 255) / 256];
+#pragma unroll
+        for (int i = 0; i < (N4 + 255) / 256; ++i) {
+            const int e = tid + i * 256;
+            tv[i] = e < NT4 ? srcT[e] : (e < N4 ? srcM[e - NT4] : make_float4(0.f, 0.f, 0.f, 0.f));
+        }
+#pragma unroll
+        for (int i = 0; i < (N4 + 255) / 256; ++i)
+            if (tid + i * 256 < N4) dst[tid + i * 256] = tv[i];
     }
     for (int i = tid; i < NWT * 32; i += 256) k0s[i] = (i < NS) ? k0p[(size_t)u * NS + i] : 0.f;
     __syncthreads();
@@ -374,7 +388,7 @@ int launch_passB(explainn_ctx* c, int B, hipStream_t s) {
     const dim3 grid((tiles + 4 * FC_BTW - 1) / (4 * FC_BTW), c->U);
 #define CALL(N)                                                                                  \
     hipLaunchKernelGGL(passB_kernel<N>, grid, dim3(256), passB_lds<N>(), s, c->ext, c->alpha,    \
-                       c->shift, c->dz, c->bits, c->Tt, c->M, c->k0p, c->mug, c->sig1, c->dy,    \
+                       c->shift, c->dz, c->bits, c->Ttf, c->Mff, c->k0p, c->mug, c->sig1, c->dy,    \
                        c->S12p, c->n, c->Bs, B)
     NQ_DISPATCH(c->NQ, CALL);
 #undef CALL

@@ -233,6 +233,7 @@ __global__ __launch_bounds__(1024) void prep2_kernel(
         }
     } else {
         double* qb = sm;
+        STAMP(0);
         float* Cs = (float*)(sm + NS);
         float* V1s = Cs + n * n;
         const int ld = n + 1;
@@ -249,8 +250,14 @@ __global__ __launch_bounds__(1024) void prep2_kernel(
         for (int e = tid; e < n * n; e += NT) {
             const int w = e / n, wp = e % n;
             double s2 = 0;
-            for (int c = 0; c < QCH; ++c)
-                s2 += (double)S2p[(((size_t)u * QCH + c) * NS + w) * NS + wp];
+            for (int c0 = 0; c0 < QCH; c0 += 8) {     // eight partials in flight, fixed-order sum
+                float pv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    pv[i] = (c0 + i < QCH) ? S2p[(((size_t)u * QCH + c0 + i) * NS + w) * NS + wp] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s2 += (double)pv[i];
+            }
             // sum (q_w - s_w)(q_w' - s_w') = S2r - s_w * S1[w']
             const double sw = (double)qs0[(size_t)u * NS + w];
             const double cov = (s2 * invB - sw * qb[wp]) - qb[w] * qb[wp];
@@ -264,6 +271,7 @@ __global__ __launch_bounds__(1024) void prep2_kernel(
             qb[w] = v;                        // from here on qb = mean of q
         }
         __syncthreads();
+        STAMP(1);
         // eight threads per hidden channel: each takes every 8th column w' of the quadratic form
         const int r = tid >> 3, part = tid & 7;
         const int rr = r < FC_H ? r : FC_H - 1;
@@ -301,6 +309,7 @@ __global__ __launch_bounds__(1024) void prep2_kernel(
                               BN_MOM_D * var * (double)B / (double)(B - 1));
         }
         if (u == 0 && tid == 0 && nbt) *nbt += 1;
+        STAMP(2);
     }
     // the same weights in MFMA A-fragment order for fc_fwd:
     // A2f[((t*NKS + s)*64) + l] = A2[32t + (l&31)][2s + (l>>5)]
@@ -311,6 +320,7 @@ __global__ __launch_bounds__(1024) void prep2_kernel(
         A2f[(size_t)u * 4 * NKS * 64 + i] =
             (r < FC_H && w < n) ? A2[((size_t)u * FC_H + r) * NS + w] : 0.f;
     }
+    STAMP(3);
 }
 
 int launch_prep2(explainn_ctx* c, const explainn_params* p, int B, bool train, hipStream_t s) {

@@ -12,6 +12,8 @@ __device__ unsigned long long g_stamps[1 << 20];
 void explainn_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vprintf(fmt, ap); va_end(ap); printf("\n"); }
 #include "../explainn_amd/csrc/prep.hip"
 #include "../explainn_amd/csrc/fc.hip"
+#include "../explainn_amd/csrc/bwd.hip"
+#include "../explainn_amd/csrc/convpool.hip"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
 static void report(const char* name, int waves, int nst, float ms) {
@@ -43,7 +45,7 @@ int main() {
     CK(hipMemcpy(A2f, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
     uint4* bits = (uint4*)dalloc((size_t)U * Bs * 16 + 64); float* z = (float*)dalloc((size_t)U * Bs * 4); float* o = (float*)dalloc((size_t)U * Bs * 4);
     float* dz = (float*)dalloc((size_t)U * Bs * 4 + 64); float* EQp = (float*)dalloc((size_t)U * ACH * 100 * NS * 4); float* Sep = (float*)dalloc((size_t)U * ACH * 100 * 4);
-    float* Tt = (float*)dalloc((size_t)(U * 100 + 2) * NS * 4); float* M = (float*)dalloc((size_t)(U * NS + 2) * NS * 4); float* k0p = (float*)dalloc(U * NS * 4);
+    float* Tt = (float*)dalloc((size_t)(U * 100 + 2) * NS * 8); float* M = (float*)dalloc((size_t)(U * NS + 2) * NS * 8); float* k0p = (float*)dalloc(U * NS * 4);
     double* mug = (double*)dalloc(U * 8); double* sig1 = (double*)dalloc(U * 8); std::vector<double> one(U, 1.0); CK(hipMemcpy(sig1, one.data(), U * 8, hipMemcpyHostToDevice));
     float* dy = (float*)dalloc((size_t)U * n * Bs * 4); float* S12p = (float*)dalloc((size_t)U * (Bs / 32) * 2 * 4);
     float* fz = (float*)dalloc(U * 4);
@@ -63,9 +65,42 @@ int main() {
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
         if (rep) report("passA", ACH * U, 4, ms);
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(passB_kernel<26>, dim3(4, U), dim3(256), passB_lds<26>(), 0, ext, alpha, shift, dz, bits, Tt, M, k0p, mug, sig1, dy, S12p, n, Bs, B);
+        hipLaunchKernelGGL(passB_kernel<26>, dim3(4, U), dim3(256), passB_lds<26>(), 0, ext, alpha, shift, dz, bits, Tt, M, k0p, mug, sig1, dy, S12p, n, Bs, B); // (tables passed as fragment-ordered stand-ins)
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
         if (rep) report("passB", 4 * U * 4, 6, ms);
+    }
+    // ---- second group: conv_pool, conv_bwd, prep2, mid_fused ----
+    {
+        const int k = 19, L = 200, NW = (L + 31) / 32 + 2, PW = 2 * NW, NT = 10, U4 = 300;
+        uint32_t* pk2 = (uint32_t*)dalloc((size_t)PW * Bs * 4); uint32_t* nmask = (uint32_t*)dalloc((size_t)NW * Bs * 4);
+        std::vector<uint32_t> hp((size_t)PW * Bs); for (auto& v : hp) v = (uint32_t)rand() * 65537u;
+        CK(hipMemcpy(pk2, hp.data(), hp.size() * 4, hipMemcpyHostToDevice));
+        float* lut = (float*)dalloc((size_t)(U4 / 2) * NT * 32 * 4); float* Wt = (float*)dalloc((size_t)(U4 / 4) * k * 20 * 4);
+        uint8_t* idx = (uint8_t*)dalloc((size_t)U * n * Bs);
+        float* Dspp = (float*)dalloc((size_t)U * (Bs / 64) * 76 * 4);
+        float* fc1_w = (float*)dalloc((size_t)U * 100 * n * 4); float* C = (float*)dalloc((size_t)U * NS * NS * 4);
+        double* qbar = (double*)dalloc((size_t)U * NS * 8); float* A2 = (float*)dalloc((size_t)U * 100 * NS * 4);
+        float* sig2 = (float*)dalloc(U * 100 * 4); std::vector<float> ones(U * 100, 1.f); CK(hipMemcpy(sig2, ones.data(), U * 100 * 4, hipMemcpyHostToDevice));
+        float* md = (float*)dalloc((size_t)U * 100 * n * 4 + 4096);
+        size_t cps = (size_t)(NT * 16 + k * 5) * 8 + (size_t)(PW + NW) * 64 * 4;
+        for (int rep = 0; rep < 2; ++rep) {
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(conv_pool_kernel<19>, dim3(16 * 2, U4 / 2), dim3(64), cps, 0, pk2, nmask, (const float2*)lut, Wt, alpha, ext, idx, n, Bs, PW, NW, 2);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep) report("conv_pool", 16 * 2 * (U4 / 2), 3, ms);
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(conv_bwd_kernel<19>, dim3(16, U), dim3(64), (size_t)(PW + NW) * 256, 0, dy, idx, pk2, nmask, Dspp, U, n, Bs, PW, NW);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep) report("conv_bwd", 16 * U, 4, ms);
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(prep2_kernel<true>, dim3(U), dim3(1024), prep2_lds(n, NS), 0, fc1_w, sh2, sh2, sh2, md, md + U * 100, (int64_t*)nullptr, qs0, S1p, S2p, qbar, C, A2, A2f, sh2, sig2, n, NS, NKS, B, QCH);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep) report("prep2", U * 16, 4, ms);
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(mid_fused_kernel, dim3(U), dim3(1024), mid_fused_lds(n), 0, EQp, Sep, A2, sh2, sig2, fc1_w, V2, sh2, qbar, C, Tt, Tt, M, M, k0p, md, md, md, md, md, n, NS, 1, 13, B, ACH, 1.4285715f);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep) report("mid_fused", U * 16, 6, ms);
+        }
     }
     return 0;
 }
