@@ -34,6 +34,17 @@ def algorithmic_bytes_per_step(B, P):
     return B * (16 * L + 8 * T) + 2 * 4 * P
 
 
+def measured_traffic():
+    """HBM bytes per step from the PMC passes committed under profiles/ (rocprofv3 cannot run inside
+    this process); None if the file is absent or was taken on another workload."""
+    path = os.path.join(ROOT, "profiles", "r01_final_traffic.json")
+    try:
+        with open(path) as fh:
+            return int(json.load(fh)["traffic_bytes_per_step"])
+    except Exception:
+        return None
+
+
 def synthetic_batch(B, seed, device):
     g = torch.Generator().manual_seed(seed)
     idx = torch.randint(0, 4, (B, L), generator=g)
@@ -162,7 +173,9 @@ def main():
                        "parameters": P, "parallelism": "dp%d" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                         "traffic": None,
+                         "traffic": measured_traffic() if world == 1 else None,
+                         "traffic_note": "bytes per step, FETCH_SIZE(x2)+WRITE_SIZE from profiles/"
+                                         "r01_final_traffic.json (separate rocprofv3 --pmc passes)",
                          "kernel": "train_step pipeline (all launches of one step)",
                          "algorithmic_bytes_per_step": alg,
                          "gpu_ms_per_step_hip_events": round(step_gpu_s * 1e3, 4)},

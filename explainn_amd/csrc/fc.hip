@@ -34,7 +34,7 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
 
 // MODE: 0 eval, 1 train without dropout, 2 train + counter-based generator, 3 train + keep-mask
 template <int NQ, int MODE>
-__global__ __launch_bounds__(256, 5) void fc_fwd_kernel(
+__global__ __launch_bounds__(256, (NQ <= 32 ? 5 : 1)) void fc_fwd_kernel(
     const float* __restrict__ ext, const float* __restrict__ alpha,
     const float* __restrict__ shift, const float* __restrict__ A2f, const float* __restrict__ sh2,
     const float* __restrict__ V2, uint4* __restrict__ bits, float* __restrict__ zout,
@@ -283,7 +283,7 @@ int launch_passA(explainn_ctx* c, int B, hipStream_t s) {
 // passB: workgroup = 4 wavefronts of one unit; T and M fragments staged in LDS
 // ---------------------------------------------------------------------------------------------
 template <int NQ>
-__global__ __launch_bounds__(256, 5) void passB_kernel(
+__global__ __launch_bounds__(256, (NQ <= 32 ? 5 : 1)) void passB_kernel(
     const float* __restrict__ ext, const float* __restrict__ alpha,
     const float* __restrict__ shift, const float* __restrict__ dz, const uint4* __restrict__ bits,
     const float* __restrict__ Ttf, const float* __restrict__ Mff, const float* __restrict__ k0p,
