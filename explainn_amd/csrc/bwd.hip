@@ -188,10 +188,14 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
         const int v = e / NS, w = e % NS;
         float acc = 0.f;
         if (v < n && w < n) {
-            double a = 0;
-            for (int r = 0; r < FC_H; ++r)
-                a = fma((double)(cfs[r] * V1s[r * ld + v]), (double)A2s[r * ld + w], a);
-            acc = (float)a;
+            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;    // four independent chains over r
+            for (int r = 0; r < FC_H; r += 4) {
+                a0 = fma((double)(cfs[r] * V1s[r * ld + v]), (double)A2s[r * ld + w], a0);
+                a1 = fma((double)(cfs[r + 1] * V1s[(r + 1) * ld + v]), (double)A2s[(r + 1) * ld + w], a1);
+                a2 = fma((double)(cfs[r + 2] * V1s[(r + 2) * ld + v]), (double)A2s[(r + 2) * ld + w], a2);
+                a3 = fma((double)(cfs[r + 3] * V1s[(r + 3) * ld + v]), (double)A2s[(r + 3) * ld + w], a3);
+            }
+            acc = (float)((a0 + a1) + (a2 + a3));
             Ms[v * n + w] = acc;
         }
         M[(size_t)u * NS * NS + e] = acc;
@@ -206,8 +210,16 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
         float tv = 0.f;
         if (w < n) {
             tv = (float)(sv * (double)A2s[r * ld + w]);
-            double hq = 0;
-            for (int v = 0; v < n; ++v) hq = fma((double)V1s[r * ld + v], (double)Cs[v * n + w], hq);
+            double h0 = 0, h1 = 0, h2 = 0, h3 = 0;    // four independent chains over v
+            int v = 0;
+            for (; v + 3 < n; v += 4) {
+                h0 = fma((double)V1s[r * ld + v], (double)Cs[v * n + w], h0);
+                h1 = fma((double)V1s[r * ld + v + 1], (double)Cs[(v + 1) * n + w], h1);
+                h2 = fma((double)V1s[r * ld + v + 2], (double)Cs[(v + 2) * n + w], h2);
+                h3 = fma((double)V1s[r * ld + v + 3], (double)Cs[(v + 3) * n + w], h3);
+            }
+            for (; v < n; ++v) h0 = fma((double)V1s[r * ld + v], (double)Cs[v * n + w], h0);
+            double hq = (h0 + h1) + (h2 + h3);
             const double sg = (double)sig2[ch];
             hq *= (double)B / sg;
             const double val = ((double)g2[ch] / sg) *

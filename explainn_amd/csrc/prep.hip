@@ -277,10 +277,21 @@ __global__ __launch_bounds__(1024) void prep2_kernel(
         const int rr = r < FC_H ? r : FC_H - 1;
         const float* v1 = V1s + rr * ld;
         double var = 0;
-        for (int wp = part; wp < n; wp += 8) {
-            double t = 0;
-            for (int w = 0; w < n; ++w) t = fma((double)v1[w], (double)Cs[w * n + wp], t);
-            var = fma(t, (double)v1[wp], var);
+        // four columns w' per pass: independent fma chains instead of one 26..160-long chain
+        for (int wp0 = part; wp0 < n; wp0 += 32) {
+            int wpi[4];
+            double t[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wpi[i] = min(wp0 + 8 * i, n - 1);
+            for (int w = 0; w < n; ++w) {
+                const double v = (double)v1[w];
+                const float* crow = Cs + w * n;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t[i] = fma(v, (double)crow[wpi[i]], t[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (wp0 + 8 * i < n) var = fma(t[i], (double)v1[wpi[i]], var);
         }
         var += __shfl_xor(var, 1, 64); var += __shfl_xor(var, 2, 64); var += __shfl_xor(var, 4, 64);
         const int ch = u * FC_H + rr;
