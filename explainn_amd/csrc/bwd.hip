@@ -276,17 +276,19 @@ int launch_mid_bwd(explainn_ctx* c, const explainn_params* p, const explainn_gra
 
 // ---------------------------------------------------------------------------------------------
 template <int K>
-__global__ __launch_bounds__(64) void conv_bwd_kernel(const float* __restrict__ dy,
-                                                      const uint8_t* __restrict__ idx,
-                                                      const uint32_t* __restrict__ pk2,
-                                                      const uint32_t* __restrict__ nmask,
-                                                      float* __restrict__ Dspp, int U, int n,
-                                                      int Bs, int PW, int NW) {
-    // One wavefront = 64 sequences x one unit; lane = sequence.  The 4K partial sums of a lane live
-    // in REGISTERS: per tap three compare-select-adds for bases C,G,T; base A is recovered at the
-    // end as (sum of all dy) - C - G - T - (dy that fell on an N).  No LDS traffic in the loop
-    // (LDS float atomics serialise per lane on gfx950, and plain LDS read-modify-write chains
-    // were latency-bound: profiles/r01_c), ~100 VGPRs -> 5 waves per SIMD.
+__global__ __launch_bounds__(64, 5) void conv_bwd_kernel(const float* __restrict__ dy,
+                                                         const uint8_t* __restrict__ idx,
+                                                         const uint32_t* __restrict__ pk2,
+                                                         const uint32_t* __restrict__ nmask,
+                                                         float* __restrict__ Dspp, int U, int n,
+                                                         int Bs, int PW, int NW) {
+    // One wavefront = 64 sequences x one unit; lane = sequence.  The partial sums of a lane live in
+    // REGISTERS: per tap three compare-select-adds for bases C,G,T; base A is recovered at the end
+    // as (sum of all dy) - C - G - T.  N positions are packed as 'C'; in the rare windows that
+    // contain one their dy is also summed wave-wide into scalar registers and taken out of C at the end.  No LDS traffic in the loop (LDS float atomics
+    // serialise per lane on gfx950 and LDS read-modify-write chains were latency-bound,
+    // profiles/r01_c); <= 102 VGPRs and 7 KB of LDS keep 5 waves per SIMD, i.e. the whole grid
+    // resident in one round at C2.
     extern __shared__ uint32_t smem[];        // pk2 tile [PW][64], nmask tile [NW][64]
     uint32_t* pks = smem;
     uint32_t* nms = smem + (size_t)PW * 64;
@@ -295,26 +297,26 @@ __global__ __launch_bounds__(64) void conv_bwd_kernel(const float* __restrict__ 
     STAMP(0);
     stage_column(pks + lane, pk2 + b, PW, Bs);
     stage_column(nms + lane, nmask + b, NW, Bs);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(1);
     constexpr uint32_t KMASK = (K >= 32) ? 0xffffffffu : ((1u << K) - 1u);
-    float a1[K], a2[K], a3[K], an[K];
+    float a1[K], a2[K], a3[K];
+    float nacc[K];                                     // wave-uniform (SGPRs)
 #pragma unroll
-    for (int j = 0; j < K; ++j) { a1[j] = 0.f; a2[j] = 0.f; a3[j] = 0.f; an[j] = 0.f; }
+    for (int j = 0; j < K; ++j) { a1[j] = 0.f; a2[j] = 0.f; a3[j] = 0.f; nacc[j] = 0.f; }
     float tot = 0.f;
-    // dy / idx for four windows are requested together: one global-load latency per four windows
-    for (int wb = 0; wb < n; wb += 4) {
-        float dyq[4];
-        int psq[4];
+    // dy / idx for two windows are requested together (more would cost the 5th wave per SIMD)
+    for (int wb = 0; wb < n; wb += 2) {
+        float dyq[2];
+        int psq[2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 2; ++q) {
             const int w = min(wb + q, n - 1);
             const size_t off = ((size_t)u * n + w) * Bs + b;
             dyq[q] = (wb + q < n) ? dy[off] : 0.f;
             psq[q] = POOLW * w + (int)idx[off];
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 2; ++q) {
             const float dyv = dyq[q];                  // 0 for windows past the end
             const int ps = psq[q];
             const int w0 = ps >> 4, sh = (ps & 15) * 2;
@@ -323,7 +325,6 @@ __global__ __launch_bounds__(64) void conv_bwd_kernel(const float* __restrict__ 
             const uint32_t lo = __funnelshift_r(c0, c1, sh), hi = __funnelshift_r(c1, c2, sh);
             const int n0 = ps >> 5, nsh = ps & 31;
             const uint32_t nm = __funnelshift_r(nms[n0 * 64 + lane], nms[(n0 + 1) * 64 + lane], nsh) & KMASK;
-            tot += dyv;
 #pragma unroll
             for (int j = 0; j < K; ++j) {
                 const uint32_t code = (j < 16 ? (lo >> (2 * j)) : (hi >> (2 * (j - 16)))) & 3u;
@@ -331,31 +332,45 @@ __global__ __launch_bounds__(64) void conv_bwd_kernel(const float* __restrict__ 
                 a2[j] += (code == 2u) ? dyv : 0.f;
                 a3[j] += (code == 3u) ? dyv : 0.f;
             }
-            if (__any(nm != 0u)) {                     // N positions are packed as code 0
+            if (__any(nm != 0u)) {
+                // rare: some lane's window holds an N.  N is packed as 'C', so its dy went into
+                // a1[j] and into tot: base A is already right (tot - a1 cancels it), and the C
+                // bucket is corrected by the wave-wide sum of those dy, kept in scalar registers
 #pragma unroll
-                for (int j = 0; j < K; ++j) an[j] += ((nm >> j) & 1u) ? dyv : 0.f;
+                for (int j = 0; j < K; ++j) {
+                    const float dn = wave_sum(((nm >> j) & 1u) ? dyv : 0.f);
+                    nacc[j] += __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, dn)));
+                }
             }
+            tot += dyv;
         }
     }
     STAMP(2);
-    // sums over the 64 lanes through LDS: every lane parks its 4K values as a column of a
-    // [4K][65] tile, then lane t adds up row t (conflict-free both ways); output (a,j) -> a*K + j
-    float* red = reinterpret_cast<float*>(smem);      // the code tiles are dead by now
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-        red[(j) * 65 + lane] = tot - an[j] - a1[j] - a2[j] - a3[j];
-        red[(K + j) * 65 + lane] = a1[j];
-        red[(2 * K + j) * 65 + lane] = a2[j];
-        red[(3 * K + j) * 65 + lane] = a3[j];
-    }
-    __syncthreads();
+    // sums over the 64 lanes through LDS, one base at a time: every lane parks K values as a column
+    // of a [K][65] tile (the code tiles are dead by now), then lane j adds up row j
+    float* red = reinterpret_cast<float*>(smem);
     float* out = Dspp + ((size_t)u * (Bs / 64) + tile) * 4 * K;
-    for (int t = lane; t < 4 * K; t += 64) {
-        float sacc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const float v = a == 0 ? (tot - a1[j] - a2[j] - a3[j]) : (a == 1 ? a1[j] : (a == 2 ? a2[j] : a3[j]));
+            red[j * 65 + lane] = v;
+        }
+        __syncthreads();
+        if (lane < K) {
+            float sacc = 0.f;
 #pragma unroll 16
-        for (int l = 0; l < 64; ++l) sacc += red[t * 65 + l];
-        out[t] = sacc;
+            for (int l = 0; l < 64; ++l) sacc += red[lane * 65 + l];
+            if (a == 1) {                              // lane j holds tap j: take its N sum out
+                float nj = 0.f;
+#pragma unroll
+                for (int j = 0; j < K; ++j) nj = (lane == j) ? nacc[j] : nj;
+                sacc -= nj;
+            }
+            out[a * K + lane] = sacc;
+        }
     }
     STAMP(3);
 }
@@ -380,7 +395,7 @@ __global__ __launch_bounds__(64) void conv_bwd_kernel(const float* __restrict__ 
 int launch_conv_bwd(explainn_ctx* c, int B, hipStream_t s) {
     const dim3 grid((B + 63) / 64, c->U);
     size_t sm = (size_t)(c->PW + c->NW) * 64 * sizeof(uint32_t);
-    const size_t red_bytes = (size_t)4 * c->k * 65 * sizeof(float);
+    const size_t red_bytes = (size_t)c->k * 65 * sizeof(float);
     if (sm < red_bytes) sm = red_bytes;
 #define CALL(KK)                                                                               \
     hipLaunchKernelGGL(conv_bwd_kernel<KK>, grid, dim3(64), sm, s, c->dy, c->idx, c->pk2, c->nmask, \

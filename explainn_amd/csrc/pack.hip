@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void pack_onehot_kernel(const float* __restric
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const uint32_t c = tile[lane][16 * q + i];
-            w2 |= (c > 3u ? 0u : c) << (2 * i);
+            w2 |= (c > 3u ? 1u : c) << (2 * i);       // N is packed as 'C'; nmask marks it (see conv_bwd)
         }
         const int wi = (p0 >> 4) + q;
         if (wi < PW) pk2[(size_t)wi * Bs + b0 + lane] = w2;
