@@ -98,6 +98,7 @@ int check_batch(const explainn_ctx* c, int B) {
 
 int eval_front(explainn_ctx* c, const float* x, int B, const explainn_params* p, hipStream_t s) {
     TRY(launch_pack(c, x, B, false, s));
+    TRY(launch_prep1_tables(c, p, s));
     TRY(launch_prep1(c, p, B, false, s));
     return EXPLAINN_OK;
 }
@@ -174,6 +175,9 @@ extern "C" int explainn_create(explainn_ctx** out, int cnn_units, int kernel_siz
         delete c;
         return EXPLAINN_E_HIP;
     }
+    HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     int rc = prep_configure(c);
     if (rc == EXPLAINN_OK) rc = bwd_configure(c);
     if (rc == EXPLAINN_OK) rc = fc_configure(c);
@@ -185,7 +189,10 @@ extern "C" int explainn_create(explainn_ctx** out, int cnn_units, int kernel_siz
 
 extern "C" void explainn_destroy(explainn_ctx* c) {
     if (!c) return;
-    if (c->base) hipFree(c->base);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->base) (void)hipFree(c->base);
     delete c;
 }
 
@@ -196,7 +203,7 @@ extern "C" int explainn_forward_eval(explainn_ctx* c, const float* x, int B,
     TRY(check_batch(c, B));
     hipStream_t s = static_cast<hipStream_t>(stream);
     TRY(eval_front(c, x, B, p, s));
-    TRY(launch_conv_pool(c, B, s));
+    TRY(launch_conv_pool(c, p, B, s));
     TRY(launch_prep2(c, p, B, false, s));
     TRY(launch_fc_fwd(c, p, B, false, nullptr, 0.f, 0, s));
     TRY(launch_head_fwd(c, p, B, false, logits, nullptr, s));
@@ -208,7 +215,7 @@ extern "C" int explainn_unit_outputs(explainn_ctx* c, const float* x, int B,
     TRY(check_batch(c, B));
     hipStream_t s = static_cast<hipStream_t>(stream);
     TRY(eval_front(c, x, B, p, s));
-    TRY(launch_conv_pool(c, B, s));
+    TRY(launch_conv_pool(c, p, B, s));
     TRY(launch_prep2(c, p, B, false, s));
     TRY(launch_fc_fwd(c, p, B, false, nullptr, 0.f, 0, s));
     TRY(launch_head_fwd(c, p, B, false, nullptr, outs, s));
@@ -240,9 +247,17 @@ extern "C" int explainn_forward_train(explainn_ctx* c, const float* x, int B,
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     c->fwd_B = 0;
-    TRY(launch_pack(c, x, B, true, s));
-    TRY(launch_prep1(c, p, B, true, s));
-    TRY(launch_conv_pool(c, B, s));
+    TRY(launch_pack(c, x, B, false, s));
+    // fork: the input-moment chain (pair counts -> Gram -> BatchNorm1 fold) needs only the packed
+    // codes, the filter bank only the filter tables and sign(gamma1): run them side by side
+    HIP_TRY(hipEventRecord(c->ev_fork, s));
+    HIP_TRY(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    TRY(launch_moments(c, B, c->side));
+    TRY(launch_prep1(c, p, B, true, c->side));
+    HIP_TRY(hipEventRecord(c->ev_join, c->side));
+    TRY(launch_prep1_tables(c, p, s));
+    TRY(launch_conv_pool(c, p, B, s));
+    HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
     TRY(launch_qmoments(c, B, s));
     TRY(launch_prep2(c, p, B, true, s));
     TRY(launch_fc_fwd(c, p, B, true, keep_mask, dropout_p, seed, s));

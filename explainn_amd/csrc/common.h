@@ -24,6 +24,8 @@ struct explainn_ctx {
     int K4;               // 4*k
     int QCH;              // b-chunks of the q-moment kernel
     int ACH;              // b-chunks of passA
+    hipStream_t side;     // second stream: input-moment chain runs beside the filter bank
+    hipEvent_t ev_fork, ev_join;
     // ---- state of the step in flight ----
     int fwd_B;            // batch of the last train forward (0 = none)
     int fwd_drop;         // dropout was active
@@ -96,7 +98,9 @@ void explainn_set_error(const char* fmt, ...);
 // ---- launchers, one per pipeline stage (defined next to their kernels) ----
 int launch_pack(explainn_ctx* c, const float* x, int B, bool counts, hipStream_t s);
 int launch_prep1(explainn_ctx* c, const explainn_params* p, int B, bool train, hipStream_t s);
-int launch_conv_pool(explainn_ctx* c, int B, hipStream_t s);
+int launch_moments(explainn_ctx* c, int B, hipStream_t s);
+int launch_prep1_tables(explainn_ctx* c, const explainn_params* p, hipStream_t s);
+int launch_conv_pool(explainn_ctx* c, const explainn_params* p, int B, hipStream_t s);
 int launch_conv_act(explainn_ctx* c, int B, float* acts, hipStream_t s);
 int launch_qmoments(explainn_ctx* c, int B, hipStream_t s);
 int launch_prep2(explainn_ctx* c, const explainn_params* p, int B, bool train, hipStream_t s);

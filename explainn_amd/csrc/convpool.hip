@@ -36,7 +36,7 @@ __global__ __launch_bounds__(64) void conv_pool_kernel(const uint32_t* __restric
                                                        const uint32_t* __restrict__ nmask,
                                                        const float2* __restrict__ lut,
                                                        const float* __restrict__ Wt,
-                                                       const float* __restrict__ alpha,
+                                                       const float* __restrict__ gamma1, int U,
                                                        float* __restrict__ ext,
                                                        uint8_t* __restrict__ idx, int n, int Bs,
                                                        int PW, int NW, int wsplit) {
@@ -66,8 +66,10 @@ __global__ __launch_bounds__(64) void conv_pool_kernel(const uint32_t* __restric
         stage_column(pks + lane, pk2 + b, PW, Bs);
         stage_column(nms + lane, nmask + b, NW, Bs);
     }
-    const float sg0 = alpha[pair * 2] >= 0.f ? 1.f : -1.f;
-    const float sg1 = alpha[pair * 2 + 1] >= 0.f ? 1.f : -1.f;
+    // sign(alpha) = sign(gamma1): the pooling direction does not need the BatchNorm statistics,
+    // so this kernel can run beside the input-moment chain
+    const float sg0 = (pair * 2 < U && gamma1[pair * 2] < 0.f) ? -1.f : 1.f;
+    const float sg1 = (pair * 2 + 1 < U && gamma1[pair * 2 + 1] < 0.f) ? -1.f : 1.f;
     __syncthreads();
     STAMP(1);
     const char* Lb = reinterpret_cast<const char*>(L2);
@@ -163,13 +165,13 @@ static size_t conv_pool_lds(const explainn_ctx* c) {
     return (size_t)(NT * 16 + c->k * 5) * sizeof(float2) + (size_t)(c->PW + c->NW) * 64 * 4;
 }
 
-int launch_conv_pool(explainn_ctx* c, int B, hipStream_t s) {
+int launch_conv_pool(explainn_ctx* c, const explainn_params* p, int B, hipStream_t s) {
     const int wsplit = c->n >= 8 ? 2 : 1;
     const dim3 grid(((B + 63) / 64) * wsplit, c->U4 / 2);
     const size_t sm = conv_pool_lds(c);
 #define CALL(KK)                                                                               \
     hipLaunchKernelGGL(conv_pool_kernel<KK>, grid, dim3(64), sm, s, c->pk2, c->nmask,          \
-                       reinterpret_cast<const float2*>(c->lut), c->Wt, c->alpha, c->ext, c->idx, \
+                       reinterpret_cast<const float2*>(c->lut), c->Wt, p->bn1_w, c->U, c->ext, c->idx, \
                        c->n, c->Bs, c->PW, c->NW, wsplit)
     K_DISPATCH(c->k, CALL);
 #undef CALL

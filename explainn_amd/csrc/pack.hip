@@ -114,13 +114,21 @@ __global__ __launch_bounds__(256) void gram_kernel(const int* __restrict__ cnt,
     }
 }
 
+int launch_moments(explainn_ctx* c, int B, hipStream_t s);
+
 int launch_pack(explainn_ctx* c, const float* x, int B, bool counts, hipStream_t s) {
     const int gb = (B + 63) / 64;
     // position tiles cover the padded tail too, so the packed words past L are written (as zeros)
     hipLaunchKernelGGL(pack_onehot_kernel, dim3(gb, (c->NW * 32 + 63) / 64), dim3(256), 0, s, x,
                        c->codesT, c->pk2, c->nmask, B, c->L, c->Bs, c->PW, c->NW, c->flags);
     LAUNCH_CHECK();
-    if (counts) {
+    if (counts) return launch_moments(c, B, s);
+    return EXPLAINN_OK;
+}
+
+// input moments (train mode): pair counts -> Gram matrix of the window indicator
+int launch_moments(explainn_ctx* c, int B, hipStream_t s) {
+    {
         const int waves = c->k * c->L;
         hipLaunchKernelGGL(pair_counts_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, c->codesT,
                            c->cnt, B, c->L, c->k, c->Bs);

@@ -3,8 +3,8 @@
 // from moments instead of from a pass over the activations.
 //
 //   prep1    BN1 (architectures/__init__.py:79): mean/var of the conv output from the input
-//            moments (m, G):  mu = cb + w.m,  var = w'Gw - (w.m)^2  -> alpha, shift; also lays
-//            the filter taps out for the conv kernel (unit quads interleaved, code 4 -> 0).
+//            moments (m, G):  mu = cb + w.m,  var = w'Gw - (w.m)^2  -> alpha, shift (prep1_stats);
+//            the filter taps laid out for the conv kernel come from prep1_tables.
 //   qtrans   q = exp(alpha*ext+shift) re-laid sequence-major for scalar-operand consumers.
 //   qmom     first/second moments of q over the batch (shifted by sequence 0 for conditioning).
 //   prep2    BN2 (architectures/__init__.py:90): mean/var of FC1's output from the q moments
@@ -20,38 +20,46 @@ __device__ __forceinline__ double block_sum_128(double v, double* red) {
     return red[0] + red[1];
 }
 
-template <bool TRAIN>
-__global__ __launch_bounds__(128) void prep1_kernel(
-    const float* __restrict__ conv_w, const float* __restrict__ conv_b,
-    const float* __restrict__ g1, const float* __restrict__ b1, float* __restrict__ rm,
-    float* __restrict__ rv, int64_t* nbt, const double* __restrict__ G,
-    const double* __restrict__ m, float* __restrict__ alpha, float* __restrict__ shift,
-    double* __restrict__ mug, double* __restrict__ sig1, double* __restrict__ Gw,
-    float* __restrict__ Wt, float* __restrict__ lut, int U, int k, int B, int Lo) {
-    __shared__ double wsh[4 * MAX_K];
-    __shared__ double red[2];
+// prep1 is split in two so that the filter-bank kernel does not wait for the input moments:
+//   prep1_tables  filter taps re-laid for the gather (Wt) + dinucleotide tables (lut)   <- W only
+//   prep1_stats   BatchNorm1 fold (alpha, shift), running statistics, G.w for the backward  <- W, m, G
+__global__ __launch_bounds__(128) void prep1_tables_kernel(const float* __restrict__ conv_w,
+                                                           float* __restrict__ Wt,
+                                                           float* __restrict__ lut, int U, int k) {
+    __shared__ float wsh[4 * MAX_K];
     const int u = blockIdx.x, tid = threadIdx.x, K4 = 4 * k;
     for (int i = tid; i < K4; i += 128) {
         const int a = i / k, j = i % k;
         const float wv = (u < U) ? conv_w[(size_t)u * K4 + i] : 0.f;
         Wt[((size_t)(u >> 2) * k + j) * 20 + a * 4 + (u & 3)] = wv;
-        wsh[i] = (double)wv;
+        wsh[i] = wv;
     }
     for (int j = tid; j < k; j += 128) Wt[((size_t)(u >> 2) * k + j) * 20 + 16 + (u & 3)] = 0.f;
     __syncthreads();
-    // dinucleotide tables for conv_pool: lut[pair][t][c0 c1].{x,y} = W[u][c0][2t] + W[u][c1][2t+1]
-    {
-        const int NT = (k + 1) / 2;
-        for (int e = tid; e < NT * 16; e += 128) {
-            const int t = e >> 4, code4 = e & 15;
-            float sum = 0.f;
-            for (int i = 0; i < 2; ++i) {
-                const int j = 2 * t + i;
-                if (j < k) sum += (float)wsh[((code4 >> (2 * i)) & 3) * k + j];
-            }
-            lut[(((size_t)(u >> 1) * NT + t) * 16 + code4) * 2 + (u & 1)] = sum;
+    // lut[pair][t][c0 c1].{x,y} = W[u][c0][2t] + W[u][c1][2t+1]
+    const int NT = (k + 1) / 2;
+    for (int e = tid; e < NT * 16; e += 128) {
+        const int t = e >> 4, code4 = e & 15;
+        float sum = 0.f;
+        for (int i = 0; i < 2; ++i) {
+            const int j = 2 * t + i;
+            if (j < k) sum += wsh[((code4 >> (2 * i)) & 3) * k + j];
         }
+        lut[(((size_t)(u >> 1) * NT + t) * 16 + code4) * 2 + (u & 1)] = sum;
     }
+}
+
+template <bool TRAIN>
+__global__ __launch_bounds__(128) void prep1_stats_kernel(
+    const float* __restrict__ conv_w, const float* __restrict__ conv_b,
+    const float* __restrict__ g1, const float* __restrict__ b1, float* __restrict__ rm,
+    float* __restrict__ rv, int64_t* nbt, const double* __restrict__ G,
+    const double* __restrict__ m, float* __restrict__ alpha, float* __restrict__ shift,
+    double* __restrict__ mug, double* __restrict__ sig1, double* __restrict__ Gw, int U, int k,
+    int B, int Lo) {
+    __shared__ double wsh[4 * MAX_K];
+    __shared__ double red[2];
+    const int u = blockIdx.x, tid = threadIdx.x, K4 = 4 * k;
     if (u >= U) {
         if (tid == 0) { alpha[u] = 0.f; shift[u] = 0.f; }
         return;
@@ -64,12 +72,17 @@ __global__ __launch_bounds__(128) void prep1_kernel(
         }
         return;
     }
+    for (int i = tid; i < K4; i += 128) wsh[i] = (double)conv_w[(size_t)u * K4 + i];
     __syncthreads();
     double mu_p = 0, q_p = 0;
     for (int i = tid; i < K4; i += 128) {
-        double gw = 0;
+        // two independent chains over the row of G
+        double g0 = 0, g1s = 0;
         const double* Gr = G + (size_t)i * K4;
-        for (int i2 = 0; i2 < K4; ++i2) gw = fma(Gr[i2], wsh[i2], gw);
+        int i2 = 0;
+        for (; i2 + 1 < K4; i2 += 2) { g0 = fma(Gr[i2], wsh[i2], g0); g1s = fma(Gr[i2 + 1], wsh[i2 + 1], g1s); }
+        for (; i2 < K4; ++i2) g0 = fma(Gr[i2], wsh[i2], g0);
+        const double gw = g0 + g1s;
         Gw[(size_t)u * K4 + i] = gw;
         mu_p = fma(wsh[i], m[i], mu_p);
         q_p = fma(wsh[i], gw, q_p);
@@ -92,15 +105,23 @@ __global__ __launch_bounds__(128) void prep1_kernel(
     }
 }
 
+int launch_prep1_tables(explainn_ctx* c, const explainn_params* p, hipStream_t s) {
+    hipLaunchKernelGGL(prep1_tables_kernel, dim3(c->U4), dim3(128), 0, s, p->conv_w, c->Wt, c->lut,
+                       c->U, c->k);
+    LAUNCH_CHECK();
+    return EXPLAINN_OK;
+}
+
 int launch_prep1(explainn_ctx* c, const explainn_params* p, int B, bool train, hipStream_t s) {
     if (train)
-        hipLaunchKernelGGL(prep1_kernel<true>, dim3(c->U4), dim3(128), 0, s, p->conv_w, p->conv_b,
-                           p->bn1_w, p->bn1_b, p->bn1_rm, p->bn1_rv, p->bn1_nbt, c->G, c->m,
-                           c->alpha, c->shift, c->mug, c->sig1, c->Gw, c->Wt, c->lut, c->U, c->k, B, c->Lo);
+        hipLaunchKernelGGL(prep1_stats_kernel<true>, dim3(c->U4), dim3(128), 0, s, p->conv_w,
+                           p->conv_b, p->bn1_w, p->bn1_b, p->bn1_rm, p->bn1_rv, p->bn1_nbt, c->G,
+                           c->m, c->alpha, c->shift, c->mug, c->sig1, c->Gw, c->U, c->k, B, c->Lo);
     else
-        hipLaunchKernelGGL(prep1_kernel<false>, dim3(c->U4), dim3(128), 0, s, p->conv_w, p->conv_b,
-                           p->bn1_w, p->bn1_b, p->bn1_rm, p->bn1_rv, (int64_t*)nullptr, c->G, c->m,
-                           c->alpha, c->shift, c->mug, c->sig1, c->Gw, c->Wt, c->lut, c->U, c->k, B, c->Lo);
+        hipLaunchKernelGGL(prep1_stats_kernel<false>, dim3(c->U4), dim3(128), 0, s, p->conv_w,
+                           p->conv_b, p->bn1_w, p->bn1_b, p->bn1_rm, p->bn1_rv, (int64_t*)nullptr,
+                           c->G, c->m, c->alpha, c->shift, c->mug, c->sig1, c->Gw, c->U, c->k, B,
+                           c->Lo);
     LAUNCH_CHECK();
     return EXPLAINN_OK;
 }

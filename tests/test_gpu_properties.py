@@ -1,0 +1,145 @@
+"""Size-independent properties of the HIP path at BASELINE.json's full C2 size (300 units, 200 bp,
+batch 1024) -- where the numpy oracle would take minutes -- plus edge cases.  -m gpu."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+from oracle import explainn_oracle as orc  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+U, K, L, T, B = 300, 19, 200, 1, 1024
+
+
+def _c2_model(seed=0, T_=T):
+    from explainn_amd import ExplaiNN
+    torch.manual_seed(seed)
+    m = ExplaiNN(U, K, L, T_).cuda()
+    with torch.no_grad():                       # move BN parameters off their defaults
+        g = torch.Generator().manual_seed(seed + 1)
+        for i in (1, 7, 11):
+            bn = m.linears[i]
+            bn.weight.copy_((1 + 0.3 * torch.randn(bn.weight.shape, generator=g)).cuda())
+            bn.bias.copy_((0.2 * torch.randn(bn.bias.shape, generator=g)).cuda())
+        m.linears[1].weight[::3] *= -1          # some units pool with min
+    m.dropout_p = 0.0
+    return m
+
+
+def _batch(seed=1, n_frac=0.002):
+    return torch.from_numpy(orc.random_onehot(B, L, seed=seed, n_frac=n_frac)).cuda()
+
+
+def _grads(m, x, y, scale=1.0):
+    m.train()
+    m.zero_grad()
+    logits = m(x)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, y) * scale
+    loss.backward()
+    return logits.detach(), [p.grad.clone() for p in m.parameters()]
+
+
+def test_c2_batch_permutation_equivariance():
+    """Permuting the sequences of a batch permutes train-mode logits the same way and leaves
+    every gradient unchanged (batch statistics and sums are order-independent up to rounding)."""
+    m = _c2_model()
+    x = _batch()
+    y = (torch.rand(B, T, generator=torch.Generator().manual_seed(3)) > 0.5).float().cuda()
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    lg1, g1 = _grads(m, x, y)
+    m.load_state_dict(sd0)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(4)).cuda()
+    lg2, g2 = _grads(m, x[perm], y[perm])
+    assert (lg1[perm] - lg2).abs().max().item() < 1e-4
+    for (name, _), a, b in zip(m.named_parameters(), g1, g2):
+        scale = max(1e-6, a.abs().max().item())
+        # the BatchNorm backward subtracts batch means from sums ~100x larger than the result, and a
+        # different lane/tile assignment changes the fp32 summation order (plus a handful of ReLU
+        # pre-activations within an ulp of zero among 30 M): 1e-3 of the tensor's max
+        assert (a - b).abs().max().item() <= 1e-3 * scale + 1e-7, name
+
+
+def test_c2_backward_is_linear_in_the_loss_gradient():
+    """backward(2*dlogits) == 2*backward(dlogits) for all 14 gradients (same forward state)."""
+    m = _c2_model()
+    x = _batch(seed=5)
+    y = (torch.rand(B, T, generator=torch.Generator().manual_seed(6)) > 0.5).float().cuda()
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    _, g1 = _grads(m, x, y, scale=1.0)
+    m.load_state_dict(sd0)
+    _, g2 = _grads(m, x, y, scale=2.0)
+    for (name, _), a, b in zip(m.named_parameters(), g1, g2):
+        scale = max(1e-6, a.abs().max().item())
+        assert (2 * a - b).abs().max().item() <= 1e-4 * scale + 1e-7, name
+
+
+def test_c2_train_mode_ignores_pre_batchnorm_biases():
+    """A bias in front of a train-mode BatchNorm cancels exactly: shifting linears.{0,6,10}.bias
+    changes no train-mode logit (their gradients are identically zero)."""
+    m = _c2_model()
+    x = _batch(seed=7)
+    m.train()
+    with torch.no_grad():
+        a = m(x).clone()
+        m.linears[0].bias += 0.37
+        m.linears[6].bias -= 0.21
+        m.linears[10].bias += 1.5
+        b = m(x)
+    assert (a - b).abs().max().item() < 1e-4
+
+
+def test_c2_eval_facade_consistency():
+    """model(x) == final(linears(x_rep)) and linears[:3] has the reference's shape, at full size
+    (test.py:148-160); predict-style strand handling: forward of the reverse complement equals
+    forward of the flipped tensor by construction."""
+    m = _c2_model().eval()
+    x = _batch(seed=8)[:256]
+    with torch.no_grad():
+        logits = m(x)
+        outs = m.linears(x.repeat(1, U, 1))
+        assert outs.shape == (256, U)
+        assert (m.final(outs) - logits).abs().max().item() < 1e-4
+        acts = m.linears[:3](x[:8].repeat(1, U, 1))
+        assert acts.shape == (8, U, L - K + 1) and torch.isfinite(acts).all()
+        # max-pool of the activations reproduces what the fused path pooled: compare through q
+        pooled = torch.nn.functional.max_pool1d(acts, 7, 7)
+        assert pooled.shape == (8, U, (L - K + 1) // 7)
+
+
+def test_c2_step_is_deterministic():
+    """Two identical steps from the same state give bitwise-identical gradients (fixed-order partial
+    sums, no float atomics)."""
+    m = _c2_model()
+    x = _batch(seed=9)
+    y = (torch.rand(B, T, generator=torch.Generator().manual_seed(10)) > 0.5).float().cuda()
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    lg1, g1 = _grads(m, x, y)
+    m.load_state_dict(sd0)
+    lg2, g2 = _grads(m, x, y)
+    assert torch.equal(lg1, lg2)
+    for (name, _), a, b in zip(m.named_parameters(), g1, g2):
+        assert torch.equal(a, b), name
+
+
+def test_edge_cases_small():
+    from explainn_amd import ExplaiNN
+    sd = orc.random_state_dict(5, 19, 200, 2, seed=2)
+    m = ExplaiNN(5, 19, 200, 2)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    m = m.cuda().eval()
+    x = orc.random_onehot(70, 200, seed=3)
+    x[3] = 0                                    # an all-N sequence (all-zero columns)
+    x[4, :, :50] = 0                            # a long N run
+    ref = orc.forward(sd, x)
+    with torch.no_grad():
+        one = m(torch.from_numpy(x[:1]).cuda())            # batch of one in eval mode is fine
+        assert np.abs(one.cpu().numpy() - ref[:1]).max() < 1e-4
+        small = m(torch.from_numpy(x[:3]).cuda())
+        big = m(torch.from_numpy(x).cuda())                # larger batch: the context grows
+        assert np.abs(small.cpu().numpy() - ref[:3]).max() < 1e-4
+        assert np.abs(big.cpu().numpy() - ref).max() < 1e-4
+        again = m(torch.from_numpy(x[:3]).cuda())
+        assert torch.equal(small, again)
+    with pytest.raises(RuntimeError, match="shape"):
+        m(torch.zeros(2, 4, 199).cuda())
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(2, 4, 200))                          # host tensor, model on device

@@ -85,7 +85,7 @@ int main() {
         size_t cps = (size_t)(NT * 16 + k * 5) * 8 + (size_t)(PW + NW) * 64 * 4;
         for (int rep = 0; rep < 2; ++rep) {
             CK(hipEventRecord(e0));
-            hipLaunchKernelGGL(conv_pool_kernel<19>, dim3(16 * 2, U4 / 2), dim3(64), cps, 0, pk2, nmask, (const float2*)lut, Wt, alpha, ext, idx, n, Bs, PW, NW, 2);
+            hipLaunchKernelGGL(conv_pool_kernel<19>, dim3(16 * 2, U4 / 2), dim3(64), cps, 0, pk2, nmask, (const float2*)lut, Wt, alpha, U, ext, idx, n, Bs, PW, NW, 2);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
             if (rep) report("conv_pool", 16 * 2 * (U4 / 2), 3, ms);
             CK(hipEventRecord(e0));
