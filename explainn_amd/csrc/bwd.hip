@@ -312,8 +312,15 @@ __global__ __launch_bounds__(64, 5) void conv_bwd_kernel(const float* __restrict
         for (int q = 0; q < 2; ++q) {
             const int w = min(wb + q, n - 1);
             const size_t off = ((size_t)u * n + w) * Bs + b;
-            dyq[q] = (wb + q < n) ? dy[off] : 0.f;
-            psq[q] = POOLW * w + (int)idx[off];
+            dyq[q] = dy[off];                          // unconditional (w is clamped)
+            psq[q] = (int)idx[off];
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { KEEP(dyq[q]); KEEP(psq[q]); }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            dyq[q] = (wb + q < n) ? dyq[q] : 0.f;
+            psq[q] += POOLW * min(wb + q, n - 1);
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {

@@ -143,6 +143,12 @@ extern __device__ unsigned long long g_stamps[];
 #define STAMP(i) do { } while (0)
 #endif
 
+// KEEP(x): pins a loaded value in a VGPR at this point.  hipcc otherwise sinks a global load into the
+// predicated block of its only use (`cond ? f(load) : 0`), which yields one `s_cbranch_execz;
+// global_load; s_waitcnt vmcnt(0)` per element -- a fully serialised fetch (22 K cycles for 26 rows).
+// Pattern: issue all loads into an array, KEEP() each element in a second loop, then compute.
+#define KEEP(x) asm volatile("" : "+v"(x))
+
 // Copy `rows` rows of a [rows][Bs] u32 array (this lane's column b) into an LDS tile [rows][64].
 // Loads are issued eight at a time before any store: a plain `for (w) tile[w] = src[w]` with a
 // runtime trip count compiles to one exposed memory round trip per row (7-8 us for 27 rows).

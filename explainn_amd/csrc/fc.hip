@@ -30,7 +30,8 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
 }
 
 #define FC_RT 4                      // r-tiles of 32 covering the 100 hidden channels
-#define FC_BTW 2                     // 32-sequence tiles per wavefront in fc_fwd / passB
+#define FC_BTW 2                     // 32-sequence tiles per wavefront in fc_fwd
+#define PB_BTW 4                     // ... in passB (128 VGPRs -> 4 waves/SIMD: the grid must fit one round)
 
 // MODE: 0 eval, 1 train without dropout, 2 train + counter-based generator, 3 train + keep-mask
 template <int NQ, int MODE>
@@ -76,11 +77,13 @@ __global__ __launch_bounds__(256, (NQ <= 32 ? 5 : 1)) void fc_fwd_kernel(
         const int b = bt * 32 + rc;
         if (bt * 32 >= B) break;                       // wave-uniform
         float qf[NKS];
+        // all loads first (unconditional, clamped rows), pinned, then exp: see KEEP in common.h
 #pragma unroll
-        for (int s = 0; s < NKS; ++s) {
-            const int w = 2 * s + kk;
-            qf[s] = (w < n) ? qval(a1, ext[((size_t)u * n + w) * Bs + b], s1) : 0.f;
-        }
+        for (int s = 0; s < NKS; ++s) qf[s] = ext[((size_t)u * n + min(2 * s + kk, n - 1)) * Bs + b];
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) KEEP(qf[s]);
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) qf[s] = (2 * s + kk < n) ? qval(a1, qf[s], s1) : 0.f;
         uint32_t rs = 0;
         if (MODE == 2)
             rs = mix32(mix32(seed_lo ^ (uint32_t)(2 * b + kk) * 0x9E3779B9U) ^
@@ -181,7 +184,7 @@ int launch_fc_fwd(explainn_ctx* c, const explainn_params* p, int B, bool train,
 // ---------------------------------------------------------------------------------------------
 #define QT_LD 65
 template <int NQ>
-__global__ __launch_bounds__(64) void passA_kernel(const float* __restrict__ ext,
+__global__ __launch_bounds__(64, 3) void passA_kernel(const float* __restrict__ ext,
                                                    const float* __restrict__ alpha,
                                                    const float* __restrict__ shift,
                                                    const float* __restrict__ dz,
@@ -214,12 +217,18 @@ __global__ __launch_bounds__(64) void passA_kernel(const float* __restrict__ ext
         const bool live = b < bend;
         const int bc = live ? b : bbeg;
 #pragma unroll
+        for (int i = 0; i < 32; ++i) rq[i] = eu[(size_t)min(wt * 32 + i, n - 1) * Bs + bc];
+        rdz = dzu[bc];
+        rw = bu[bc];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) KEEP(rq[i]);
+        KEEP(rdz);
+#pragma unroll
         for (int i = 0; i < 32; ++i) {
             const int w = wt * 32 + i;
-            rq[i] = (live && w < n) ? qval(a1, eu[(size_t)w * Bs + bc], sh1) : 0.f;
+            rq[i] = (live && w < n) ? qval(a1, rq[i], sh1) : 0.f;
         }
-        rdz = live ? dzu[bc] : 0.f;
-        rw = bu[bc];
+        rdz = live ? rdz : 0.f;
     };
     STAMP(0);
     if (bbeg < bend) fetch(bbeg);
@@ -283,7 +292,7 @@ int launch_passA(explainn_ctx* c, int B, hipStream_t s) {
 // passB: workgroup = 4 wavefronts of one unit; T and M fragments staged in LDS
 // ---------------------------------------------------------------------------------------------
 template <int NQ>
-__global__ __launch_bounds__(256, (NQ <= 32 ? 5 : 1)) void passB_kernel(
+__global__ __launch_bounds__(256, (NQ <= 32 ? 4 : 1)) void passB_kernel(
     const float* __restrict__ ext, const float* __restrict__ alpha,
     const float* __restrict__ shift, const float* __restrict__ dz, const uint4* __restrict__ bits,
     const float* __restrict__ Ttf, const float* __restrict__ Mff, const float* __restrict__ k0p,
@@ -320,17 +329,18 @@ __global__ __launch_bounds__(256, (NQ <= 32 ? 5 : 1)) void passB_kernel(
     const float a1 = alpha[u], s1 = shift[u];
     const float mu = (float)mug[u];
     const float isg = (float)(1.0 / sig1[u]);
-    for (int it = 0; it < FC_BTW; ++it) {
-        const int bt = (blockIdx.x * 4 + wave) * FC_BTW + it;
+    for (int it = 0; it < PB_BTW; ++it) {
+        const int bt = (blockIdx.x * 4 + wave) * PB_BTW + it;
         if (bt * 32 >= B) break;                       // wave-uniform
         const int b = bt * 32 + rc;
         const bool live = b < B;
         float nqf[NKS];
 #pragma unroll
-        for (int s = 0; s < NKS; ++s) {
-            const int w = 2 * s + kk;
-            nqf[s] = (w < n) ? -qval(a1, ext[((size_t)u * n + w) * Bs + b], s1) : 0.f;
-        }
+        for (int s = 0; s < NKS; ++s) nqf[s] = ext[((size_t)u * n + min(2 * s + kk, n - 1)) * Bs + b];
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) KEEP(nqf[s]);
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) nqf[s] = (2 * s + kk < n) ? -qval(a1, nqf[s], s1) : 0.f;
         const uint4 wv = bits[(size_t)u * Bs + b];
         const float dzb = dz[(size_t)u * Bs + b];
         const uint32_t wds[4] = {wv.x, wv.y, wv.z, wv.w};
@@ -353,17 +363,23 @@ __global__ __launch_bounds__(256, (NQ <= 32 ? 5 : 1)) void passB_kernel(
             for (int s = 0; s < NKS; ++s) acc = MFMA32(Mf[(wt * NKS + s) * 64 + lane], nqf[s], acc);
             if (it == 0 && wt == 0) STAMP(3);
             // D[w][b]: lane holds its sequence b, rows w = wt*32 + (g&3) + 8(g>>2) + 4kk
+            float exv[16];
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {                 // all 16 loads first, unconditional
+                const int w = wt * 32 + (g & 3) + 8 * (g >> 2) + 4 * kk;
+                exv[g] = ext[((size_t)u * n + min(w, n - 1)) * Bs + b];
+            }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) KEEP(exv[g]);
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const int w = wt * 32 + (g & 3) + 8 * (g >> 2) + 4 * kk;
-                if (w < n) {
-                    const float ex = ext[((size_t)u * n + w) * Bs + b];
-                    const float qv = qval(a1, ex, s1);
-                    const float dyv = live ? acc[g] * qv : 0.f;
-                    sA += dyv;
-                    sB = fmaf(dyv, (ex - mu) * isg, sB);
-                    dy[((size_t)u * n + w) * Bs + b] = dyv;
-                }
+                const float ex = exv[g];
+                const float qv = qval(a1, ex, s1);
+                const float dyv = (live && w < n) ? acc[g] * qv : 0.f;
+                sA += dyv;
+                sB = fmaf(dyv, (ex - mu) * isg, sB);
+                if (w < n) dy[((size_t)u * n + w) * Bs + b] = dyv;
             }
         }
         if (it == 0) STAMP(4);
@@ -385,7 +401,7 @@ static size_t passB_lds() {
 
 int launch_passB(explainn_ctx* c, int B, hipStream_t s) {
     const int tiles = (B + 31) / 32;
-    const dim3 grid((tiles + 4 * FC_BTW - 1) / (4 * FC_BTW), c->U);
+    const dim3 grid((tiles + 4 * PB_BTW - 1) / (4 * PB_BTW), c->U);
 #define CALL(N)                                                                                  \
     hipLaunchKernelGGL(passB_kernel<N>, grid, dim3(256), passB_lds<N>(), s, c->ext, c->alpha,    \
                        c->shift, c->dz, c->bits, c->Ttf, c->Mff, c->k0p, c->mug, c->sig1, c->dy,    \

@@ -155,7 +155,8 @@ __global__ __launch_bounds__(64) void qmom_kernel(
     const float a1 = alpha[u], sh1 = shift[u];
     const float* eu = ext + (size_t)u * n * Bs;
     const int wB = wt2 * 32 + rc;
-    const float sB = (wB < n) ? qval(a1, eu[(size_t)wB * Bs], sh1) : 0.f;    // q of sequence 0
+    const float sBraw = eu[(size_t)min(wB, n - 1) * Bs];
+    const float sB = (wB < n) ? qval(a1, sBraw, sh1) : 0.f;                  // q of sequence 0
     if (ch == 0 && wt == 0 && kk == 0 && wB < NS) qs0[(size_t)u * NS + wB] = sB;
     f32x16q acc;
 #pragma unroll
@@ -165,16 +166,28 @@ __global__ __launch_bounds__(64) void qmom_kernel(
     auto fetch = [&](int b0) {
         const int b = b0 + lane;
         const bool live = b < bend;
+        const int bcl = live ? b : bbeg;
+        // all row loads are issued together (unconditional, clamped addresses), pinned, then used
+#pragma unroll
+        for (int i = 0; i < 32; ++i) ra[i] = eu[(size_t)min(wt * 32 + i, n - 1) * Bs + bcl];
+        if (NWT > 1 && !same) {
+#pragma unroll
+            for (int i = 0; i < (NWT > 1 ? 32 : 1); ++i) rb[i] = eu[(size_t)min(wt2 * 32 + i, n - 1) * Bs + bcl];
+        }
+#pragma unroll
+        for (int i = 0; i < 32; ++i) KEEP(ra[i]);
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
             const int w = wt * 32 + i;
-            ra[i] = (live && w < n) ? qval(a1, eu[(size_t)w * Bs + b], sh1) : 0.f;
+            ra[i] = (live && w < n) ? qval(a1, ra[i], sh1) : 0.f;
         }
         if (NWT > 1 && !same) {
 #pragma unroll
+            for (int i = 0; i < (NWT > 1 ? 32 : 1); ++i) KEEP(rb[i]);
+#pragma unroll
             for (int i = 0; i < (NWT > 1 ? 32 : 1); ++i) {
                 const int w = wt2 * 32 + i;
-                rb[i] = (live && w < n) ? qval(a1, eu[(size_t)w * Bs + b], sh1) : 0.f;
+                rb[i] = (live && w < n) ? qval(a1, rb[i], sh1) : 0.f;
             }
         }
     };
