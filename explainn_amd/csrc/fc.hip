@@ -31,7 +31,7 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
 
 #define FC_RT 4                      // r-tiles of 32 covering the 100 hidden channels
 #define FC_BTW 2                     // 32-sequence tiles per wavefront in fc_fwd
-#define PB_BTW 4                     // ... in passB (128 VGPRs -> 4 waves/SIMD: the grid must fit one round)
+#define PB_BTW 2                     // ... in passB
 
 // MODE: 0 eval, 1 train without dropout, 2 train + counter-based generator, 3 train + keep-mask
 template <int NQ, int MODE>
@@ -292,7 +292,7 @@ int launch_passA(explainn_ctx* c, int B, hipStream_t s) {
 // passB: workgroup = 4 wavefronts of one unit; T and M fragments staged in LDS
 // ---------------------------------------------------------------------------------------------
 template <int NQ>
-__global__ __launch_bounds__(256, (NQ <= 32 ? 4 : 1)) void passB_kernel(
+__global__ __launch_bounds__(256, (NQ <= 32 ? 5 : 1)) void passB_kernel(
     const float* __restrict__ ext, const float* __restrict__ alpha,
     const float* __restrict__ shift, const float* __restrict__ dz, const uint4* __restrict__ bits,
     const float* __restrict__ Ttf, const float* __restrict__ Mff, const float* __restrict__ k0p,
@@ -363,23 +363,30 @@ __global__ __launch_bounds__(256, (NQ <= 32 ? 4 : 1)) void passB_kernel(
             for (int s = 0; s < NKS; ++s) acc = MFMA32(Mf[(wt * NKS + s) * 64 + lane], nqf[s], acc);
             if (it == 0 && wt == 0) STAMP(3);
             // D[w][b]: lane holds its sequence b, rows w = wt*32 + (g&3) + 8(g>>2) + 4kk
-            float exv[16];
+            // epilogue in two halves of eight rows: eight unconditional loads in flight at a time
+            // (sixteen would push the kernel past the register budget of 5 waves per SIMD)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {                 // all 16 loads first, unconditional
-                const int w = wt * 32 + (g & 3) + 8 * (g >> 2) + 4 * kk;
-                exv[g] = ext[((size_t)u * n + min(w, n - 1)) * Bs + b];
-            }
+            for (int h = 0; h < 2; ++h) {
+                float exv[8];
 #pragma unroll
-            for (int g = 0; g < 16; ++g) KEEP(exv[g]);
+                for (int g8 = 0; g8 < 8; ++g8) {
+                    const int g = h * 8 + g8;
+                    const int w = wt * 32 + (g & 3) + 8 * (g >> 2) + 4 * kk;
+                    exv[g8] = ext[((size_t)u * n + min(w, n - 1)) * Bs + b];
+                }
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int w = wt * 32 + (g & 3) + 8 * (g >> 2) + 4 * kk;
-                const float ex = exv[g];
-                const float qv = qval(a1, ex, s1);
-                const float dyv = (live && w < n) ? acc[g] * qv : 0.f;
-                sA += dyv;
-                sB = fmaf(dyv, (ex - mu) * isg, sB);
-                if (w < n) dy[((size_t)u * n + w) * Bs + b] = dyv;
+                for (int g8 = 0; g8 < 8; ++g8) KEEP(exv[g8]);
+#pragma unroll
+                for (int g8 = 0; g8 < 8; ++g8) {
+                    const int g = h * 8 + g8;
+                    const int w = wt * 32 + (g & 3) + 8 * (g >> 2) + 4 * kk;
+                    const float ex = exv[g8];
+                    const float qv = qval(a1, ex, s1);
+                    const float dyv = (live && w < n) ? acc[g] * qv : 0.f;
+                    sA += dyv;
+                    sB = fmaf(dyv, (ex - mu) * isg, sB);
+                    if (w < n) dy[((size_t)u * n + w) * Bs + b] = dyv;
+                }
             }
         }
         if (it == 0) STAMP(4);
