@@ -146,9 +146,11 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
             float pv[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                pv[i] = (c0 + i < ACH) ? EQp[(((size_t)u * ACH + c0 + i) * FC_H + r) * NS + w] : 0.f;
+                pv[i] = EQp[(((size_t)u * ACH + min(c0 + i, ACH - 1)) * FC_H + r) * NS + w];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) eq += (double)pv[i];
+            for (int i = 0; i < 8; ++i) KEEP(pv[i]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) eq += (c0 + i < ACH) ? (double)pv[i] : 0.0;
         }
         EQl[r * ld + w] = (float)eq;
     }
@@ -423,14 +425,29 @@ __global__ __launch_bounds__(128) void fin_bwd_kernel(
     const int NT = Bs / 64, nt = (B + 63) / 64;
     const int NT32 = Bs / 32, nt32 = (B + 31) / 32;
     double S1 = 0, S2 = 0;
-    for (int t = 0; t < nt32; ++t) {
-        S1 += (double)S12p[((size_t)u * NT32 + t) * 2];
-        S2 += (double)S12p[((size_t)u * NT32 + t) * 2 + 1];
+    for (int t0 = 0; t0 < nt32; t0 += 8) {
+        float2 pv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            pv[q] = *reinterpret_cast<const float2*>(&S12p[((size_t)u * NT32 + min(t0 + q, nt32 - 1)) * 2]);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { KEEP(pv[q].x); KEEP(pv[q].y); }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (t0 + q < nt32) { S1 += (double)pv[q].x; S2 += (double)pv[q].y; }
     }
     const double sg = sig1[u], a = (double)g1[u] / sg, mu = mug[u];
     for (int i = tid; i < K4; i += 128) {
         double D = 0;
-        for (int t = 0; t < nt; ++t) D += (double)Dspp[((size_t)u * NT + t) * K4 + i];
+        for (int t0 = 0; t0 < nt; t0 += 8) {           // eight partials in flight, fixed-order sum
+            float pv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) pv[q] = Dspp[((size_t)u * NT + min(t0 + q, nt - 1)) * K4 + i];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) KEEP(pv[q]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) D += (t0 + q < nt) ? (double)pv[q] : 0.0;
+        }
         const double val = a * (D - S1 * m[i] - (S2 / sg) * (Gw[(size_t)u * K4 + i] - mu * m[i]));
         g_conv_w[(size_t)u * K4 + i] = (u < freeze_n) ? 0.f : (float)val;
     }

@@ -20,18 +20,35 @@ __global__ __launch_bounds__(256) void pack_onehot_kernel(const float* __restric
     const int b0 = blockIdx.x * 64, p0 = blockIdx.y * 64;
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     int bad = 0;
-    for (int i = q; i < 64; i += 4) {
-        const int b = b0 + i, p = p0 + lane;
-        uint8_t code = (p < L) ? 4 : 0;             // N for padding lanes, 'A' past the sequence end
-        if (b < B && p < L) {
-            const float* xp = x + (size_t)b * 4 * L + p;
-            const float v0 = xp[0], v1 = xp[L], v2 = xp[2 * (size_t)L], v3 = xp[3 * (size_t)L];
-            const int ones = (v0 == 1.f) + (v1 == 1.f) + (v2 == 1.f) + (v3 == 1.f);
-            const int zeros = (v0 == 0.f) + (v1 == 0.f) + (v2 == 0.f) + (v3 == 0.f);
-            if (ones == 1 && zeros == 3) code = v0 == 1.f ? 0 : (v1 == 1.f ? 1 : (v2 == 1.f ? 2 : 3));
-            else if (zeros != 4) bad = 1;       // neither one-hot nor N: treated as N, flagged
+    const int p = p0 + lane;
+    const int pc = min(p, L - 1);
+    // four sequences (16 loads) per pass, all issued before any is used (see KEEP in common.h)
+    for (int i0 = q; i0 < 64; i0 += 16) {
+        float v[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int bc = min(b0 + i0 + 4 * r, B - 1);
+            const float* xp = x + (size_t)bc * 4 * L + pc;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) v[r][a] = xp[(size_t)a * L];
         }
-        tile[i][lane] = code;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) KEEP(v[r][a]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + 4 * r, b = b0 + i;
+            uint8_t code = (p < L) ? 4 : 0;         // N for padding lanes, 'A' past the sequence end
+            if (b < B && p < L) {
+                const float v0 = v[r][0], v1 = v[r][1], v2 = v[r][2], v3 = v[r][3];
+                const int ones = (v0 == 1.f) + (v1 == 1.f) + (v2 == 1.f) + (v3 == 1.f);
+                const int zeros = (v0 == 0.f) + (v1 == 0.f) + (v2 == 0.f) + (v3 == 0.f);
+                if (ones == 1 && zeros == 3) code = v0 == 1.f ? 0 : (v1 == 1.f ? 1 : (v2 == 1.f ? 2 : 3));
+                else if (zeros != 4) bad = 1;   // neither one-hot nor N: treated as N, flagged
+            }
+            tile[i][lane] = code;
+        }
     }
     __syncthreads();
     for (int pp = q; pp < 64; pp += 4) {
@@ -74,14 +91,23 @@ __global__ __launch_bounds__(256) void pair_counts_kernel(const uint8_t* __restr
     if (q + d < L) {
         const uint8_t* r0 = codesT + (size_t)q * Bs;
         const uint8_t* r1 = codesT + (size_t)(q + d) * Bs;
-        for (int b = lane; b < ((B + 63) & ~63); b += 64) {
-            int id = -1;
-            if (b < B) {
-                const int s0 = r0[b], s1 = r1[b];
-                if (s0 < 4 && s1 < 4) id = s0 * 4 + s1;
+        for (int bb = lane; bb < ((B + 63) & ~63); bb += 256) {
+            int s0v[4], s1v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                  // eight byte loads in flight
+                const int bc = min(bb + 64 * r, B - 1);
+                s0v[r] = r0[bc];
+                s1v[r] = r1[bc];
             }
 #pragma unroll
-            for (int i = 0; i < 16; ++i) c[i] += __popcll(__ballot(id == i));
+            for (int r = 0; r < 4; ++r) { KEEP(s0v[r]); KEEP(s1v[r]); }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int id = -1;
+                if (bb + 64 * r < B && s0v[r] < 4 && s1v[r] < 4) id = s0v[r] * 4 + s1v[r];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) c[i] += __popcll(__ballot(id == i));
+            }
         }
     }
     int mine = 0;

@@ -288,9 +288,11 @@ __global__ __launch_bounds__(1024) void prep2_kernel(
                 float pv[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
-                    pv[i] = (c0 + i < QCH) ? S2p[(((size_t)u * QCH + c0 + i) * NS + w) * NS + wp] : 0.f;
+                    pv[i] = S2p[(((size_t)u * QCH + min(c0 + i, QCH - 1)) * NS + w) * NS + wp];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) s2 += (double)pv[i];
+                for (int i = 0; i < 8; ++i) KEEP(pv[i]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s2 += (c0 + i < QCH) ? (double)pv[i] : 0.0;
             }
             // sum (q_w - s_w)(q_w' - s_w') = S2r - s_w * S1[w']
             const double sw = (double)qs0[(size_t)u * NS + w];
