@@ -139,8 +139,10 @@ extern __device__ unsigned long long g_stamps[];
         if ((threadIdx.x & 63) == 0)                                                              \
             g_stamps[((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * (blockDim.x / 64) + threadIdx.x / 64) * 8 + (i)] = t_; \
     } while (0)
+#define STAMP_AFTER_LOADS(i) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(i); } while (0)
 #else
 #define STAMP(i) do { } while (0)
+#define STAMP_AFTER_LOADS(i) do { } while (0)
 #endif
 
 // KEEP(x): pins a loaded value in a VGPR at this point.  hipcc otherwise sinks a global load into the

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256, (NQ <= 32 ? 5 : 1)) void fc_fwd_kernel(
                        mix32(seed_hi + (uint32_t)u)) | 1u;
         const uint8_t* km = (MODE == 3) ? keep_mask + (size_t)min(b, B - 1) * FC_H * U + (size_t)u * FC_H
                                         : nullptr;
-        if (it == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(2); }
+        if (it == 0) STAMP_AFTER_LOADS(2);
         float zp = 0.f;
         uint32_t words[FC_RT];
 #pragma unroll
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256, (NQ <= 32 ? 5 : 1)) void passB_kernel(
         const float dzb = dz[(size_t)u * Bs + b];
         const uint32_t wds[4] = {wv.x, wv.y, wv.z, wv.w};
         float sA = 0.f, sB = 0.f;
-        if (it == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(2); }
+        if (it == 0) STAMP_AFTER_LOADS(2);
 #pragma unroll
         for (int wt = 0; wt < NWT; ++wt) {
             f32x16 acc;
