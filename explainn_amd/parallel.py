@@ -44,7 +44,15 @@ class GradAllReduce:
     def __init__(self, flat):
         self.flat = flat
         self.n = world()
-        self.native_avg = dist.is_initialized() and dist.get_backend() == "nccl"
+        self.native_avg = False
+        if self.n > 1 and dist.get_backend() == "nccl":
+            # ReduceOp.AVG saves the scaling pass; probe it once (all ranks take the same branch)
+            try:
+                probe = torch.ones(1, device=flat.device)
+                dist.all_reduce(probe, op=dist.ReduceOp.AVG)
+                self.native_avg = abs(float(probe.item()) - 1.0) < 1e-6
+            except Exception:
+                self.native_avg = False
 
     def __call__(self, flat=None):
         t = self.flat if flat is None else flat
