@@ -246,6 +246,159 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
     STAMP(5);
 }
 
+// Same algebra for large pooled lengths (72 < n <= 160, configs C4/C5): V1 and A2 stay in LDS
+// (2 x 100 x (n+1) floats), the EQ sums go through global memory (EQs), C is streamed through LDS in
+// 32-column chunks, and the k0' correction uses  sum_v qbar[v] M[v][w] = sum_r cf[r] (V1[r].qbar) A2[r][w]
+// so M itself never has to be resident.
+__global__ __launch_bounds__(1024) void mid_big_kernel(
+    const float* __restrict__ EQp, const float* __restrict__ Sep, const float* __restrict__ A2,
+    const float* __restrict__ sh2, const float* __restrict__ sig2, const float* __restrict__ fc1_w,
+    const float* __restrict__ fc2_w, const float* __restrict__ g2, const double* __restrict__ qbar,
+    const float* __restrict__ C, float* __restrict__ EQs, float* __restrict__ Tt,
+    float* __restrict__ Ttf, float* __restrict__ M, float* __restrict__ Mff,
+    float* __restrict__ k0p, float* __restrict__ g_fc2_w, float* __restrict__ g_bn2_w,
+    float* __restrict__ g_bn2_b, float* __restrict__ g_fc1_b, float* __restrict__ g_fc1_w, int n,
+    int NS, int NWT, int NKS, int B, int ACH, float scale) {
+    extern __shared__ float bsm[];
+    const int ld = n + 1;
+    float* V1s = bsm;                        // [100][ld]
+    float* A2s = V1s + FC_H * ld;            // [100][ld]
+    float* Cc = A2s + FC_H * ld;             // [n][32]   one column chunk of C
+    float* qb = Cc + n * 32;                 // [n]
+    float* se = qb + n;                      // [100]
+    float* md2s = se + FC_H;                 // [100]
+    float* cfs = md2s + FC_H;                // [100]  md2h / sig2
+    float* md2hs = cfs + FC_H;               // [100]
+    float* kco = md2hs + FC_H;               // [100]  md2 - cf * (V1[r].qbar)
+    const int u = blockIdx.x, tid = threadIdx.x;
+    constexpr int NT = 1024;
+    for (int e = tid; e < FC_H * n; e += NT) {
+        const int r = e / n, w = e % n;
+        const size_t ch = (size_t)u * FC_H + r;
+        V1s[r * ld + w] = fc1_w[ch * n + w];
+        A2s[r * ld + w] = A2[ch * NS + w];
+        double eq = 0;
+        for (int c0 = 0; c0 < ACH; c0 += 8) {         // eight partials in flight, fixed-order sum
+            float pv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                pv[i] = EQp[(((size_t)u * ACH + min(c0 + i, ACH - 1)) * FC_H + r) * NS + w];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) KEEP(pv[i]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) eq += (c0 + i < ACH) ? (double)pv[i] : 0.0;
+        }
+        EQs[ch * NS + w] = (float)eq;
+    }
+    for (int w = tid; w < n; w += NT) qb[w] = (float)qbar[(size_t)u * NS + w];
+    for (int r = tid; r < FC_H; r += NT) {
+        double s = 0;
+        for (int c = 0; c < ACH; ++c) s += (double)Sep[((size_t)u * ACH + c) * FC_H + r];
+        se[r] = (float)s;
+    }
+    __syncthreads();                         // (also orders this block's EQs writes before its reads)
+    const double sc = (double)scale;
+    // per-channel sums: 8 threads per channel, shuffle-reduced
+    {
+        const int r = tid >> 3, part = tid & 7;
+        const int rr = r < FC_H ? r : FC_H - 1;
+        const size_t ch = (size_t)u * FC_H + rr;
+        double sAE = 0, sVE = 0, qv = 0;
+        const double ser = (double)se[rr];
+        for (int w = part; w < n; w += 8) {
+            const double eq = (double)EQs[ch * NS + w];
+            const double qw = qbar[(size_t)u * NS + w];
+            sAE = fma((double)A2s[rr * ld + w], eq, sAE);
+            sVE = fma((double)V1s[rr * ld + w], eq - ser * qw, sVE);
+            qv = fma((double)V1s[rr * ld + w], qw, qv);
+        }
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) {
+            sAE += __shfl_xor(sAE, off, 64); sVE += __shfl_xor(sVE, off, 64); qv += __shfl_xor(qv, off, 64);
+        }
+        if (r < FC_H && part == 0) {
+            const double v2 = (double)fc2_w[ch], sg = (double)sig2[ch];
+            g_fc2_w[ch] = (float)(sc * (sAE + (double)sh2[ch] * ser));
+            const double db2 = sc * v2 * ser, dg2 = sc * v2 / sg * sVE;
+            g_bn2_b[ch] = (float)db2;
+            g_bn2_w[ch] = (float)dg2;
+            g_fc1_b[ch] = 0.f;
+            md2s[r] = (float)(db2 / (double)B);
+            md2hs[r] = (float)(dg2 / (double)B);
+            const double cf = (dg2 / (double)B) / sg;
+            cfs[r] = (float)cf;
+            kco[r] = (float)(db2 / (double)B - cf * qv);
+        }
+    }
+    __syncthreads();
+    // M[v][w] = sum_r cf[r] V1[r][v] A2[r][w]  (fp32, four chains; its consumer passB is fp32)
+    for (int e = tid; e < NS * NS; e += NT) {
+        const int v = e / NS, w = e % NS;
+        float acc = 0.f;
+        if (v < n && w < n) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            for (int r = 0; r < FC_H; r += 4) {
+                a0 = fmaf(cfs[r] * V1s[r * ld + v], A2s[r * ld + w], a0);
+                a1 = fmaf(cfs[r + 1] * V1s[(r + 1) * ld + v], A2s[(r + 1) * ld + w], a1);
+                a2 = fmaf(cfs[r + 2] * V1s[(r + 2) * ld + v], A2s[(r + 2) * ld + w], a2);
+                a3 = fmaf(cfs[r + 3] * V1s[(r + 3) * ld + v], A2s[(r + 3) * ld + w], a3);
+            }
+            acc = (a0 + a1) + (a2 + a3);
+        }
+        M[(size_t)u * NS * NS + e] = acc;
+        if ((v >> 1) < NKS)
+            Mff[(size_t)u * NWT * NKS * 64 + ((size_t)(w >> 5) * NKS + (v >> 1)) * 64 + (v & 1) * 32 + (w & 31)] = acc;
+    }
+    // dV1 and T, one 32-column chunk of C at a time
+    for (int w0 = 0; w0 < NS; w0 += 32) {
+        __syncthreads();
+        for (int e = tid; e < n * 32; e += NT) {
+            const int v = e >> 5, wc = e & 31;
+            Cc[e] = (w0 + wc < n) ? C[(size_t)u * NS * NS + (size_t)v * NS + w0 + wc] : 0.f;
+        }
+        __syncthreads();
+        for (int e = tid; e < FC_H * 32; e += NT) {
+            const int r = e >> 5, wc = e & 31, w = w0 + wc;
+            if (w >= NS) continue;
+            const size_t ch = (size_t)u * FC_H + r;
+            const double sv = sc * (double)fc2_w[ch];
+            float tv = 0.f;
+            if (w < n) {
+                tv = (float)(sv * (double)A2s[r * ld + w]);
+                double h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+                int v = 0;
+                for (; v + 3 < n; v += 4) {
+                    h0 = fma((double)V1s[r * ld + v], (double)Cc[v * 32 + wc], h0);
+                    h1 = fma((double)V1s[r * ld + v + 1], (double)Cc[(v + 1) * 32 + wc], h1);
+                    h2 = fma((double)V1s[r * ld + v + 2], (double)Cc[(v + 2) * 32 + wc], h2);
+                    h3 = fma((double)V1s[r * ld + v + 3], (double)Cc[(v + 3) * 32 + wc], h3);
+                }
+                for (; v < n; ++v) h0 = fma((double)V1s[r * ld + v], (double)Cc[v * 32 + wc], h0);
+                double hq = (h0 + h1) + (h2 + h3);
+                const double sg = (double)sig2[ch];
+                hq *= (double)B / sg;
+                const double val = ((double)g2[ch] / sg) *
+                                   (sv * (double)EQs[ch * NS + w] -
+                                    (double)md2s[r] * (double)B * qbar[(size_t)u * NS + w] -
+                                    (double)md2hs[r] * hq);
+                g_fc1_w[ch * n + w] = (float)val;
+            }
+            Tt[ch * NS + w] = tv;
+            Ttf[(size_t)u * NWT * (FC_H / 2) * 64 + ((size_t)(w >> 5) * (FC_H / 2) + (r >> 1)) * 64 + (r & 1) * 32 + (w & 31)] = tv;
+        }
+    }
+    for (int w = tid; w < NS; w += NT) {
+        double k0 = 0;
+        if (w < n)
+            for (int r = 0; r < FC_H; ++r) k0 = fma((double)A2s[r * ld + w], (double)kco[r], k0);
+        k0p[(size_t)u * NS + w] = (float)k0;
+    }
+}
+
+static size_t mid_big_lds(int n) {
+    return ((size_t)2 * FC_H * (n + 1) + (size_t)n * 32 + n + 5 * FC_H) * sizeof(float);
+}
+
 static size_t mid_fused_lds(int n) {
     return ((size_t)3 * FC_H * (n + 1) + (size_t)2 * n * n + n + 4 * FC_H) * sizeof(float);
 }
@@ -261,17 +414,11 @@ int launch_mid_bwd(explainn_ctx* c, const explainn_params* p, const explainn_gra
         LAUNCH_CHECK();
         return EXPLAINN_OK;
     }
-    hipLaunchKernelGGL(mid1_kernel, dim3(c->U), dim3(128), 0, s, c->EQp, c->Sep, c->A2, c->sh2,
-                       c->sig2, p->fc1_w, p->fc2_w, c->qbar, c->EQs, c->md2, c->md2h, g->fc2_w,
-                       g->bn2_w, g->bn2_b, g->fc1_b, c->n, c->NS, B, c->ACH, c->fwd_scale);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(mid2a_kernel, dim3(c->U), dim3(256), 0, s, c->EQs, c->A2, c->sig2, p->fc1_w,
-                       p->fc2_w, p->bn2_w, c->qbar, c->C, c->md2, c->md2h, c->Tt, c->Ttf, g->fc1_w, c->n,
-                       c->NS, (c->NQ + 31) / 32, B, c->fwd_scale);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(mid2b_kernel, dim3(c->U), dim3(256), (size_t)c->n * c->n * sizeof(float), s,
-                       c->A2, c->sig2, p->fc1_w, c->qbar, c->md2, c->md2h, c->M, c->Mff, c->k0p, c->n,
-                       c->NS, (c->NQ + 31) / 32, (c->NQ + 1) / 2);
+    hipLaunchKernelGGL(mid_big_kernel, dim3(c->U), dim3(1024), mid_big_lds(c->n), s, c->EQp, c->Sep,
+                       c->A2, c->sh2, c->sig2, p->fc1_w, p->fc2_w, p->bn2_w, c->qbar, c->C, c->EQs,
+                       c->Tt, c->Ttf, c->M, c->Mff, c->k0p, g->fc2_w, g->bn2_w, g->bn2_b, g->fc1_b,
+                       g->fc1_w, c->n, c->NS, (c->NQ + 31) / 32, (c->NQ + 1) / 2, B, c->ACH,
+                       c->fwd_scale);
     LAUNCH_CHECK();
     return EXPLAINN_OK;
 }
@@ -472,6 +619,10 @@ int bwd_configure(explainn_ctx* c) {
     if (sm > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mid2b_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+    if (c->n > 72)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mid_big_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)mid_big_lds(c->n)));
     if (c->n <= 72 && mid_fused_lds(c->n) > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mid_fused_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,

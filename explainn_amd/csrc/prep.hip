@@ -128,7 +128,7 @@ int launch_prep1(explainn_ctx* c, const explainn_params* p, int B, bool train, h
 
 // ---------------------------------------------------------------------------------------------
 // qmom: first/second moments of q over the batch on the exact-fp32 matrix core.
-//   S1[w'] = sum_b (q[b,w'] - s[w']),   S2r[w][w'] = sum_b q[b,w] (q[b,w'] - s[w']),  s = q of sequence 0
+//   S1[w'] = sum_b (q[b,w'] - s[w']),   S2[w][w'] = sum_b (q[b,w] - s[w]) (q[b,w'] - s[w']),  s = q of sequence 0
 // One wavefront per (unit, batch chunk, 32x32 tile of (w,w')).  The sequence index is the MFMA K
 // dimension (two sequences per v_mfma_f32_32x32x2_f32), but ext is stored batch-fastest, so each
 // super-tile of 64 sequences is fetched with coalesced row loads (lane = sequence), turned into
@@ -158,6 +158,8 @@ __global__ __launch_bounds__(64) void qmom_kernel(
     const float sBraw = eu[(size_t)min(wB, n - 1) * Bs];
     const float sB = (wB < n) ? qval(a1, sBraw, sh1) : 0.f;                  // q of sequence 0
     if (ch == 0 && wt == 0 && kk == 0 && wB < NS) qs0[(size_t)u * NS + wB] = sB;
+    const float sAraw = eu[(size_t)min(wt * 32 + rc, n - 1) * Bs];
+    const float sA = (wt * 32 + rc < n) ? qval(a1, sAraw, sh1) : 0.f;     // shift of the A rows
     f32x16q acc;
 #pragma unroll
     for (int g = 0; g < 16; ++g) acc[g] = 0.f;
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(64) void qmom_kernel(
         for (int s = 0; s < ks; ++s) {
             const int col = 2 * s + kk;
             const bool live = b0 + col < bend;
-            const float a = tA[rc * QT_LD + col];
+            const float a = (live && wt * 32 + rc < n) ? tA[rc * QT_LD + col] - sA : 0.f;
             const float bq = (live && wB < n) ? srcB[rc * QT_LD + col] - sB : 0.f;
             s1 += bq;
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc, 0, 0, 0);
@@ -228,11 +230,112 @@ __global__ __launch_bounds__(64) void qmom_kernel(
     STAMP(3);
 }
 
+// Large pooled lengths (n > 32): ONE wavefront per (unit, batch chunk) computes every 32x32 tile of
+// the symmetric moment matrix (upper triangle, mirrored on output) from rows staged once in LDS;
+// with a wave per tile pair the same rows were fetched 11 times over.
+template <int NQ>
+__global__ __launch_bounds__(64) void qmom_big_kernel(
+    const float* __restrict__ ext, const float* __restrict__ alpha,
+    const float* __restrict__ shift, float* __restrict__ qs0, float* __restrict__ S1p,
+    float* __restrict__ S2p, int n, int Bs, int B, int QCH) {
+    constexpr int NS = ns_stride(NQ), NWT = (NQ + 31) / 32, NP = NWT * (NWT + 1) / 2;
+    extern __shared__ float qsm[];                     // rows [NWT*32][65], then s0 [NWT*32]
+    float* tile = qsm;
+    float* s0s = qsm + NWT * 32 * QT_LD;
+    const int u = blockIdx.y, ch = blockIdx.x, lane = threadIdx.x;
+    const int rc = lane & 31, kk = lane >> 5;
+    const int per = ((((B + QCH - 1) / QCH) + 63) / 64) * 64;
+    const int bbeg = ch * per, bend = min(B, bbeg + per);
+    const float a1 = alpha[u], sh1 = shift[u];
+    const float* eu = ext + (size_t)u * n * Bs;
+    for (int w = lane; w < NWT * 32; w += 64) {
+        const float raw = eu[(size_t)min(w, n - 1) * Bs];
+        const float sv = (w < n) ? qval(a1, raw, sh1) : 0.f;
+        s0s[w] = sv;
+        if (ch == 0 && w < NS) qs0[(size_t)u * NS + w] = sv;
+    }
+    __syncthreads();
+    f32x16q acc[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc[p][g] = 0.f;
+    float s1[NWT];
+#pragma unroll
+    for (int t = 0; t < NWT; ++t) s1[t] = 0.f;
+    for (int b0 = bbeg; b0 < bend; b0 += 64) {
+        const int b = b0 + lane;
+        const bool live = b < bend;
+        const int bcl = live ? b : bbeg;
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NWT; ++t) {                // stage 32 rows at a time (shifted values)
+            float r[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) r[i] = eu[(size_t)min(t * 32 + i, n - 1) * Bs + bcl];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) KEEP(r[i]);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int w = t * 32 + i;
+                tile[w * QT_LD + lane] = (live && w < n) ? qval(a1, r[i], sh1) - s0s[w] : 0.f;
+            }
+        }
+        __syncthreads();
+        const int ks = (min(bend - b0, 64) + 1) >> 1;
+        for (int s = 0; s < ks; ++s) {
+            const int col = 2 * s + kk;
+            float a[NWT];
+#pragma unroll
+            for (int t = 0; t < NWT; ++t) { a[t] = tile[(t * 32 + rc) * QT_LD + col]; s1[t] += a[t]; }
+            int p = 0;
+#pragma unroll
+            for (int t = 0; t < NWT; ++t)
+#pragma unroll
+                for (int t2 = t; t2 < NWT; ++t2, ++p)
+                    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], a[t2], acc[p], 0, 0, 0);
+        }
+    }
+    // D[w][w']: lane holds column w' = t2*32+rc, rows w = t*32 + (g&3) + 8(g>>2) + 4kk; mirror it
+    float* out = S2p + ((size_t)u * QCH + ch) * NS * NS;
+    int p = 0;
+#pragma unroll
+    for (int t = 0; t < NWT; ++t)
+#pragma unroll
+        for (int t2 = t; t2 < NWT; ++t2, ++p) {
+            const int wB = t2 * 32 + rc;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int w = t * 32 + (g & 3) + 8 * (g >> 2) + 4 * kk;
+                if (w < NS && wB < NS) {
+                    out[(size_t)w * NS + wB] = acc[p][g];
+                    if (t2 != t) out[(size_t)wB * NS + w] = acc[p][g];
+                }
+            }
+        }
+#pragma unroll
+    for (int t = 0; t < NWT; ++t) {
+        const float sv = s1[t] + __shfl_xor(s1[t], 32, 64);
+        const int w = t * 32 + rc;
+        if (kk == 0 && w < NS) S1p[((size_t)u * QCH + ch) * NS + w] = sv;
+    }
+}
+
+template <int NQ>
+static size_t qmom_big_lds() {
+    constexpr int NWT = (NQ + 31) / 32;
+    return (size_t)(NWT * 32 * QT_LD + NWT * 32) * sizeof(float);
+}
+
 int launch_qmoments(explainn_ctx* c, int B, hipStream_t s) {
 #define CALL(N)                                                                                  \
-    hipLaunchKernelGGL(qmom_kernel<N>, dim3(c->QCH, c->U, ((N + 31) / 32) * ((N + 31) / 32)),    \
-                       dim3(64), 0, s, c->ext, c->alpha, c->shift, c->qs0, c->qS1p, c->qS2p,     \
-                       c->n, c->Bs, B, c->QCH)
+    if ((N) <= 32)                                                                               \
+        hipLaunchKernelGGL(qmom_kernel<N>, dim3(c->QCH, c->U, 1), dim3(64), 0, s, c->ext,        \
+                           c->alpha, c->shift, c->qs0, c->qS1p, c->qS2p, c->n, c->Bs, B, c->QCH); \
+    else                                                                                         \
+        hipLaunchKernelGGL(qmom_big_kernel<N>, dim3(c->QCH, c->U), dim3(64), qmom_big_lds<N>(), s, \
+                           c->ext, c->alpha, c->shift, c->qs0, c->qS1p, c->qS2p, c->n, c->Bs, B,  \
+                           c->QCH)
     NQ_DISPATCH(c->NQ, CALL);
 #undef CALL
     LAUNCH_CHECK();
@@ -294,9 +397,8 @@ __global__ __launch_bounds__(1024) void prep2_kernel(
 #pragma unroll
                 for (int i = 0; i < 8; ++i) s2 += (c0 + i < QCH) ? (double)pv[i] : 0.0;
             }
-            // sum (q_w - s_w)(q_w' - s_w') = S2r - s_w * S1[w']
-            const double sw = (double)qs0[(size_t)u * NS + w];
-            const double cov = (s2 * invB - sw * qb[wp]) - qb[w] * qb[wp];
+            // S2 holds sum (q_w - s_w)(q_w' - s_w'); qb = mean of (q - s)
+            const double cov = s2 * invB - qb[w] * qb[wp];
             Cs[e] = (float)cov;
             C[(size_t)u * NS * NS + (size_t)w * NS + wp] = (float)cov;
         }
@@ -387,6 +489,13 @@ int launch_prep2(explainn_ctx* c, const explainn_params* p, int B, bool train, h
 
 // dynamic LDS above 64 KiB has to be opted into per kernel (n >= 127 needs it for the C tile)
 int prep_configure(explainn_ctx* c) {
+#define CALL(N)                                                                               \
+    if ((N) > 32 && qmom_big_lds<N>() > 48 * 1024)                                            \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&qmom_big_kernel<N>),        \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,               \
+                                    (int)qmom_big_lds<N>()))
+    NQ_DISPATCH(c->NQ, CALL);
+#undef CALL
     const size_t sm = prep2_lds(c->n, c->NS);
     if (sm > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&prep2_kernel<true>),
