@@ -53,6 +53,7 @@ void carve(explainn_ctx* c, Carver& cv) {
     cv.take(&c->qS2p, U * c->QCH * NS * NS);
     cv.take(&c->qbar, U * NS);
     cv.take(&c->C, U * NS * NS);
+    cv.take(&c->VC, U * FC_H * NS);
     cv.take(&c->A2, U * FC_H * NS);
     cv.take(&c->A2f, U * 4 * ((c->NQ + 1) / 2) * 64);
     cv.take(&c->sh2, U * FC_H);

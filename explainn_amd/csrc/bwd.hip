@@ -118,7 +118,7 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
     const float* __restrict__ EQp, const float* __restrict__ Sep, const float* __restrict__ A2,
     const float* __restrict__ sh2, const float* __restrict__ sig2, const float* __restrict__ fc1_w,
     const float* __restrict__ fc2_w, const float* __restrict__ g2, const double* __restrict__ qbar,
-    const float* __restrict__ C, float* __restrict__ Tt, float* __restrict__ Ttf,
+    const float* __restrict__ VC, float* __restrict__ Tt, float* __restrict__ Ttf,
     float* __restrict__ M, float* __restrict__ Mff, float* __restrict__ k0p, float* __restrict__ g_fc2_w, float* __restrict__ g_bn2_w,
     float* __restrict__ g_bn2_b, float* __restrict__ g_fc1_b, float* __restrict__ g_fc1_w, int n,
     int NS, int NWT, int NKS, int B, int ACH, float scale) {
@@ -127,8 +127,7 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
     float* V1s = fsm;                        // [100][ld]
     float* A2s = V1s + FC_H * ld;            // [100][ld]
     float* EQl = A2s + FC_H * ld;            // [100][ld]
-    float* Cs = EQl + FC_H * ld;             // [n][n]
-    float* Ms = Cs + n * n;                  // [n][n]
+    float* Ms = EQl + FC_H * ld;             // [n][n]
     float* qb = Ms + n * n;                  // [n]
     float* se = qb + n;                      // [100]
     float* md2s = se + FC_H;                 // [100]
@@ -154,7 +153,6 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
         }
         EQl[r * ld + w] = (float)eq;
     }
-    for (int e = tid; e < n * n; e += 1024) Cs[e] = C[(size_t)u * NS * NS + (size_t)(e / n) * NS + (e % n)];
     for (int w = tid; w < n; w += 1024) qb[w] = (float)qbar[(size_t)u * NS + w];
     for (int r = tid; r < FC_H; r += 1024) {
         double s = 0;
@@ -212,16 +210,7 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
         float tv = 0.f;
         if (w < n) {
             tv = (float)(sv * (double)A2s[r * ld + w]);
-            double h0 = 0, h1 = 0, h2 = 0, h3 = 0;    // four independent chains over v
-            int v = 0;
-            for (; v + 3 < n; v += 4) {
-                h0 = fma((double)V1s[r * ld + v], (double)Cs[v * n + w], h0);
-                h1 = fma((double)V1s[r * ld + v + 1], (double)Cs[(v + 1) * n + w], h1);
-                h2 = fma((double)V1s[r * ld + v + 2], (double)Cs[(v + 2) * n + w], h2);
-                h3 = fma((double)V1s[r * ld + v + 3], (double)Cs[(v + 3) * n + w], h3);
-            }
-            for (; v < n; ++v) h0 = fma((double)V1s[r * ld + v], (double)Cs[v * n + w], h0);
-            double hq = (h0 + h1) + (h2 + h3);
+            double hq = (double)VC[ch * NS + w];       // (V1.C)[r][w], computed once by prep2
             const double sg = (double)sig2[ch];
             hq *= (double)B / sg;
             const double val = ((double)g2[ch] / sg) *
@@ -254,7 +243,7 @@ __global__ __launch_bounds__(1024) void mid_big_kernel(
     const float* __restrict__ EQp, const float* __restrict__ Sep, const float* __restrict__ A2,
     const float* __restrict__ sh2, const float* __restrict__ sig2, const float* __restrict__ fc1_w,
     const float* __restrict__ fc2_w, const float* __restrict__ g2, const double* __restrict__ qbar,
-    const float* __restrict__ C, float* __restrict__ EQs, float* __restrict__ Tt,
+    const float* __restrict__ VC, float* __restrict__ EQs, float* __restrict__ Tt,
     float* __restrict__ Ttf, float* __restrict__ M, float* __restrict__ Mff,
     float* __restrict__ k0p, float* __restrict__ g_fc2_w, float* __restrict__ g_bn2_w,
     float* __restrict__ g_bn2_b, float* __restrict__ g_fc1_b, float* __restrict__ g_fc1_w, int n,
@@ -263,8 +252,7 @@ __global__ __launch_bounds__(1024) void mid_big_kernel(
     const int ld = n + 1;
     float* V1s = bsm;                        // [100][ld]
     float* A2s = V1s + FC_H * ld;            // [100][ld]
-    float* Cc = A2s + FC_H * ld;             // [n][32]   one column chunk of C
-    float* qb = Cc + n * 32;                 // [n]
+    float* qb = A2s + FC_H * ld;             // [n]
     float* se = qb + n;                      // [100]
     float* md2s = se + FC_H;                 // [100]
     float* cfs = md2s + FC_H;                // [100]  md2h / sig2
@@ -349,43 +337,24 @@ __global__ __launch_bounds__(1024) void mid_big_kernel(
         if ((v >> 1) < NKS)
             Mff[(size_t)u * NWT * NKS * 64 + ((size_t)(w >> 5) * NKS + (v >> 1)) * 64 + (v & 1) * 32 + (w & 31)] = acc;
     }
-    // dV1 and T, one 32-column chunk of C at a time
-    for (int w0 = 0; w0 < NS; w0 += 32) {
-        __syncthreads();
-        for (int e = tid; e < n * 32; e += NT) {
-            const int v = e >> 5, wc = e & 31;
-            Cc[e] = (w0 + wc < n) ? C[(size_t)u * NS * NS + (size_t)v * NS + w0 + wc] : 0.f;
+    // dV1 and T; (V1.C)[r][w] was computed once by prep2
+    for (int e = tid; e < FC_H * NS; e += NT) {
+        const int r = e / NS, w = e % NS;
+        const size_t ch = (size_t)u * FC_H + r;
+        const double sv = sc * (double)fc2_w[ch];
+        float tv = 0.f;
+        if (w < n) {
+            tv = (float)(sv * (double)A2s[r * ld + w]);
+            const double sg = (double)sig2[ch];
+            const double hq = (double)VC[ch * NS + w] * (double)B / sg;
+            const double val = ((double)g2[ch] / sg) *
+                               (sv * (double)EQs[ch * NS + w] -
+                                (double)md2s[r] * (double)B * qbar[(size_t)u * NS + w] -
+                                (double)md2hs[r] * hq);
+            g_fc1_w[ch * n + w] = (float)val;
         }
-        __syncthreads();
-        for (int e = tid; e < FC_H * 32; e += NT) {
-            const int r = e >> 5, wc = e & 31, w = w0 + wc;
-            if (w >= NS) continue;
-            const size_t ch = (size_t)u * FC_H + r;
-            const double sv = sc * (double)fc2_w[ch];
-            float tv = 0.f;
-            if (w < n) {
-                tv = (float)(sv * (double)A2s[r * ld + w]);
-                double h0 = 0, h1 = 0, h2 = 0, h3 = 0;
-                int v = 0;
-                for (; v + 3 < n; v += 4) {
-                    h0 = fma((double)V1s[r * ld + v], (double)Cc[v * 32 + wc], h0);
-                    h1 = fma((double)V1s[r * ld + v + 1], (double)Cc[(v + 1) * 32 + wc], h1);
-                    h2 = fma((double)V1s[r * ld + v + 2], (double)Cc[(v + 2) * 32 + wc], h2);
-                    h3 = fma((double)V1s[r * ld + v + 3], (double)Cc[(v + 3) * 32 + wc], h3);
-                }
-                for (; v < n; ++v) h0 = fma((double)V1s[r * ld + v], (double)Cc[v * 32 + wc], h0);
-                double hq = (h0 + h1) + (h2 + h3);
-                const double sg = (double)sig2[ch];
-                hq *= (double)B / sg;
-                const double val = ((double)g2[ch] / sg) *
-                                   (sv * (double)EQs[ch * NS + w] -
-                                    (double)md2s[r] * (double)B * qbar[(size_t)u * NS + w] -
-                                    (double)md2hs[r] * hq);
-                g_fc1_w[ch * n + w] = (float)val;
-            }
-            Tt[ch * NS + w] = tv;
-            Ttf[(size_t)u * NWT * (FC_H / 2) * 64 + ((size_t)(w >> 5) * (FC_H / 2) + (r >> 1)) * 64 + (r & 1) * 32 + (w & 31)] = tv;
-        }
+        Tt[ch * NS + w] = tv;
+        Ttf[(size_t)u * NWT * (FC_H / 2) * 64 + ((size_t)(w >> 5) * (FC_H / 2) + (r >> 1)) * 64 + (r & 1) * 32 + (w & 31)] = tv;
     }
     for (int w = tid; w < NS; w += NT) {
         double k0 = 0;
@@ -396,11 +365,11 @@ __global__ __launch_bounds__(1024) void mid_big_kernel(
 }
 
 static size_t mid_big_lds(int n) {
-    return ((size_t)2 * FC_H * (n + 1) + (size_t)n * 32 + n + 5 * FC_H) * sizeof(float);
+    return ((size_t)2 * FC_H * (n + 1) + n + 5 * FC_H) * sizeof(float);
 }
 
 static size_t mid_fused_lds(int n) {
-    return ((size_t)3 * FC_H * (n + 1) + (size_t)2 * n * n + n + 4 * FC_H) * sizeof(float);
+    return ((size_t)3 * FC_H * (n + 1) + (size_t)n * n + n + 4 * FC_H) * sizeof(float);
 }
 
 int launch_mid_bwd(explainn_ctx* c, const explainn_params* p, const explainn_grads* g, int B,
@@ -408,14 +377,14 @@ int launch_mid_bwd(explainn_ctx* c, const explainn_params* p, const explainn_gra
     if (c->n <= 72) {
         hipLaunchKernelGGL(mid_fused_kernel, dim3(c->U), dim3(1024), mid_fused_lds(c->n), s, c->EQp,
                            c->Sep, c->A2, c->sh2, c->sig2, p->fc1_w, p->fc2_w, p->bn2_w, c->qbar,
-                           c->C, c->Tt, c->Ttf, c->M, c->Mff, c->k0p, g->fc2_w, g->bn2_w, g->bn2_b,
+                           c->VC, c->Tt, c->Ttf, c->M, c->Mff, c->k0p, g->fc2_w, g->bn2_w, g->bn2_b,
                            g->fc1_b, g->fc1_w, c->n, c->NS, (c->NQ + 31) / 32, (c->NQ + 1) / 2, B, c->ACH,
                            c->fwd_scale);
         LAUNCH_CHECK();
         return EXPLAINN_OK;
     }
     hipLaunchKernelGGL(mid_big_kernel, dim3(c->U), dim3(1024), mid_big_lds(c->n), s, c->EQp, c->Sep,
-                       c->A2, c->sh2, c->sig2, p->fc1_w, p->fc2_w, p->bn2_w, c->qbar, c->C, c->EQs,
+                       c->A2, c->sh2, c->sig2, p->fc1_w, p->fc2_w, p->bn2_w, c->qbar, c->VC, c->EQs,
                        c->Tt, c->Ttf, c->M, c->Mff, c->k0p, g->fc2_w, g->bn2_w, g->bn2_b, g->fc1_b,
                        g->fc1_w, c->n, c->NS, (c->NQ + 31) / 32, (c->NQ + 1) / 2, B, c->ACH,
                        c->fwd_scale);

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(1024) void prep2_kernel(
     const float* __restrict__ g2, const float* __restrict__ b2, float* __restrict__ rm2,
     float* __restrict__ rv2, int64_t* nbt, const float* __restrict__ qs0,
     const float* __restrict__ S1p, const float* __restrict__ S2p, double* __restrict__ qbar,
-    float* __restrict__ C, float* __restrict__ A2, float* __restrict__ A2f,
+    float* __restrict__ C, float* __restrict__ VC, float* __restrict__ A2, float* __restrict__ A2f,
     float* __restrict__ sh2, float* __restrict__ sig2, int n, int NS, int NKS, int B, int QCH) {
     extern __shared__ double sm[];            // qb[NS] (double) | Cs[n][n] | V1s[100][n+1]
     const int u = blockIdx.x, tid = threadIdx.x;
@@ -429,7 +429,11 @@ __global__ __launch_bounds__(1024) void prep2_kernel(
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (wp0 + 8 * i < n) var = fma(t[i], (double)v1[wpi[i]], var);
+                if (wp0 + 8 * i < n) {
+                    var = fma(t[i], (double)v1[wpi[i]], var);
+                    // V1.C is also what the backward needs (hq in the mid kernels): keep it
+                    if (r < FC_H) VC[((size_t)u * FC_H + r) * NS + wpi[i]] = (float)t[i];
+                }
         }
         var += __shfl_xor(var, 1, 64); var += __shfl_xor(var, 2, 64); var += __shfl_xor(var, 4, 64);
         const int ch = u * FC_H + rr;
@@ -476,12 +480,12 @@ int launch_prep2(explainn_ctx* c, const explainn_params* p, int B, bool train, h
     if (train)
         hipLaunchKernelGGL(prep2_kernel<true>, dim3(c->U), dim3(1024), prep2_lds(c->n, c->NS), s,
                            p->fc1_w, p->fc1_b, p->bn2_w, p->bn2_b, p->bn2_rm, p->bn2_rv, p->bn2_nbt,
-                           c->qs0, c->qS1p, c->qS2p, c->qbar, c->C, c->A2, c->A2f, c->sh2, c->sig2,
+                           c->qs0, c->qS1p, c->qS2p, c->qbar, c->C, c->VC, c->A2, c->A2f, c->sh2, c->sig2,
                            c->n, c->NS, (c->NQ + 1) / 2, B, c->QCH);
     else
         hipLaunchKernelGGL(prep2_kernel<false>, dim3(c->U), dim3(1024), 0, s, p->fc1_w, p->fc1_b,
                            p->bn2_w, p->bn2_b, p->bn2_rm, p->bn2_rv, (int64_t*)nullptr, c->qs0,
-                           c->qS1p, c->qS2p, c->qbar, c->C, c->A2, c->A2f, c->sh2, c->sig2, c->n,
+                           c->qS1p, c->qS2p, c->qbar, c->C, c->VC, c->A2, c->A2f, c->sh2, c->sig2, c->n,
                            c->NS, (c->NQ + 1) / 2, B, c->QCH);
     LAUNCH_CHECK();
     return EXPLAINN_OK;
