@@ -52,7 +52,6 @@ void carve(explainn_ctx* c, Carver& cv) {
     cv.take(&c->qS1p, U * c->QCH * NS);
     cv.take(&c->qS2p, U * c->QCH * NS * NS);
     cv.take(&c->qbar, U * NS);
-    cv.take(&c->C, U * NS * NS);
     cv.take(&c->VC, U * FC_H * NS);
     cv.take(&c->A2, U * FC_H * NS);
     cv.take(&c->A2f, U * 4 * ((c->NQ + 1) / 2) * 64);
@@ -172,7 +171,7 @@ extern "C" int explainn_create(explainn_ctx** out, int cnn_units, int kernel_siz
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
         explainn_set_error("scratch memset failed: %s", hipGetErrorString(e));
-        hipFree(c->base);
+        (void)hipFree(c->base);
         delete c;
         return EXPLAINN_E_HIP;
     }
@@ -183,7 +182,7 @@ extern "C" int explainn_create(explainn_ctx** out, int cnn_units, int kernel_siz
     if (rc == EXPLAINN_OK) rc = bwd_configure(c);
     if (rc == EXPLAINN_OK) rc = fc_configure(c);
     if (rc == EXPLAINN_OK) rc = conv_configure(c);
-    if (rc != EXPLAINN_OK) { hipFree(c->base); delete c; return rc; }
+    if (rc != EXPLAINN_OK) { (void)hipFree(c->base); delete c; return rc; }
     *out = c;
     return EXPLAINN_OK;
 }

@@ -239,6 +239,8 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
 // (2 x 100 x (n+1) floats), the EQ sums go through global memory (EQs), C is streamed through LDS in
 // 32-column chunks, and the k0' correction uses  sum_v qbar[v] M[v][w] = sum_r cf[r] (V1[r].qbar) A2[r][w]
 // so M itself never has to be resident.
+typedef float f32x16b __attribute__((ext_vector_type(16)));
+
 __global__ __launch_bounds__(1024) void mid_big_kernel(
     const float* __restrict__ EQp, const float* __restrict__ Sep, const float* __restrict__ A2,
     const float* __restrict__ sh2, const float* __restrict__ sig2, const float* __restrict__ fc1_w,
@@ -319,23 +321,39 @@ __global__ __launch_bounds__(1024) void mid_big_kernel(
         }
     }
     __syncthreads();
-    // M[v][w] = sum_r cf[r] V1[r][v] A2[r][w]  (fp32, four chains; its consumer passB is fp32)
-    for (int e = tid; e < NS * NS; e += NT) {
-        const int v = e / NS, w = e % NS;
-        float acc = 0.f;
-        if (v < n && w < n) {
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-            for (int r = 0; r < FC_H; r += 4) {
-                a0 = fmaf(cfs[r] * V1s[r * ld + v], A2s[r * ld + w], a0);
-                a1 = fmaf(cfs[r + 1] * V1s[(r + 1) * ld + v], A2s[(r + 1) * ld + w], a1);
-                a2 = fmaf(cfs[r + 2] * V1s[(r + 2) * ld + v], A2s[(r + 2) * ld + w], a2);
-                a3 = fmaf(cfs[r + 3] * V1s[(r + 3) * ld + v], A2s[(r + 3) * ld + w], a3);
+    // M[v][w] = sum_r cf[r] V1[r][v] A2[r][w] on the matrix cores (fp32 MFMA; its consumer passB is
+    // fp32 too): NWT x NWT tiles of 32x32, K = 100 hidden channels in steps of 2, a tile per wave
+    {
+        const int wave = tid >> 6, lane = tid & 63, rc = lane & 31, kk = lane >> 5;
+        const int NT2 = (NS + 31) >> 5;
+        for (int tile = wave; tile < NT2 * NT2; tile += NT / 64) {
+            const int vt = tile / NT2, wt = tile % NT2;
+            const int va = 32 * vt + rc, wb = 32 * wt + rc;
+            const bool alive = va < n, blive = wb < n;
+            const float* acol = V1s + min(va, n - 1);
+            const float* bcol = A2s + min(wb, n - 1);
+            f32x16b acc;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+#pragma unroll 5
+            for (int s2 = 0; s2 < FC_H / 2; ++s2) {
+                const int r = 2 * s2 + kk;
+                const float a = alive ? cfs[r] * acol[r * ld] : 0.f;
+                const float bb = blive ? bcol[r * ld] : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc, 0, 0, 0);
             }
-            acc = (a0 + a1) + (a2 + a3);
+            if (wb < NS) {
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int v = 32 * vt + (g & 3) + 8 * (g >> 2) + 4 * kk;
+                    if (v < NS) {
+                        M[(size_t)u * NS * NS + (size_t)v * NS + wb] = acc[g];
+                        if ((v >> 1) < NKS)
+                            Mff[(size_t)u * NWT * NKS * 64 + ((size_t)(wb >> 5) * NKS + (v >> 1)) * 64 + (v & 1) * 32 + (wb & 31)] = acc[g];
+                    }
+                }
+            }
         }
-        M[(size_t)u * NS * NS + e] = acc;
-        if ((v >> 1) < NKS)
-            Mff[(size_t)u * NWT * NKS * 64 + ((size_t)(w >> 5) * NKS + (v >> 1)) * 64 + (v & 1) * 32 + (w & 31)] = acc;
     }
     // dV1 and T; (V1.C)[r][w] was computed once by prep2
     for (int e = tid; e < FC_H * NS; e += NT) {

@@ -53,7 +53,6 @@ struct explainn_ctx {
     float* qS1p;          // [U][QCH][NS]
     float* qS2p;          // [U][QCH][NS][NS]
     double* qbar;         // [U][NS]
-    float* C;             // [U][NS][NS]      centred covariance of q over the batch
     float* VC;            // [U][100][NS]     V1 . C  (BN2 variance in prep2, BN2 backward in mid)
     float* A2;            // [U][100][NS]     FC1 weights with BN2 folded in
     float* A2f;           // [U][4][NKS][64]  the same in MFMA A-fragment order (fc_fwd stages it)

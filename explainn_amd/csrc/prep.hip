@@ -349,13 +349,15 @@ static size_t prep2_lds(int n, int NS) {
     return (size_t)NS * sizeof(double) + ((size_t)n * n + (size_t)FC_H * (n + 1)) * sizeof(float);
 }
 
+constexpr int PREP2_MFMA_MIN_N = 72;   // above this the V1.C product runs on the MFMA (fp32)
+
 template <bool TRAIN>
 __global__ __launch_bounds__(1024) void prep2_kernel(
     const float* __restrict__ fc1_w, const float* __restrict__ fc1_b,
     const float* __restrict__ g2, const float* __restrict__ b2, float* __restrict__ rm2,
     float* __restrict__ rv2, int64_t* nbt, const float* __restrict__ qs0,
     const float* __restrict__ S1p, const float* __restrict__ S2p, double* __restrict__ qbar,
-    float* __restrict__ C, float* __restrict__ VC, float* __restrict__ A2, float* __restrict__ A2f,
+    float* __restrict__ VC, float* __restrict__ A2, float* __restrict__ A2f,
     float* __restrict__ sh2, float* __restrict__ sig2, int n, int NS, int NKS, int B, int QCH) {
     extern __shared__ double sm[];            // qb[NS] (double) | Cs[n][n] | V1s[100][n+1]
     const int u = blockIdx.x, tid = threadIdx.x;
@@ -400,7 +402,6 @@ __global__ __launch_bounds__(1024) void prep2_kernel(
             // S2 holds sum (q_w - s_w)(q_w' - s_w'); qb = mean of (q - s)
             const double cov = s2 * invB - qb[w] * qb[wp];
             Cs[e] = (float)cov;
-            C[(size_t)u * NS * NS + (size_t)w * NS + wp] = (float)cov;
         }
         __syncthreads();
         for (int w = tid; w < n; w += NT) {
@@ -415,25 +416,58 @@ __global__ __launch_bounds__(1024) void prep2_kernel(
         const int rr = r < FC_H ? r : FC_H - 1;
         const float* v1 = V1s + rr * ld;
         double var = 0;
-        // four columns w' per pass: independent fma chains instead of one 26..160-long chain
-        for (int wp0 = part; wp0 < n; wp0 += 32) {
-            int wpi[4];
-            double t[4] = {0, 0, 0, 0};
+        if (n > PREP2_MFMA_MIN_N) {
+            // large n: VC = V1 . C on the matrix cores (fp32 MFMA, 32x32 tiles: 4 row tiles of hidden
+            // channels x NWT column tiles, K = n in steps of 2), one tile per wave per pass
+            const int wave = tid >> 6, lane = tid & 63, rc = lane & 31, kk = lane >> 5;
+            const int NWT = (n + 31) >> 5;
+            for (int tile = wave; tile < 4 * NWT; tile += NT / 64) {
+                const int t = tile / NWT, wt = tile % NWT;
+                const int ra = 32 * t + rc, wb = 32 * wt + rc;
+                const float* arow = V1s + min(ra, FC_H - 1) * ld;
+                const float* bcol = Cs + min(wb, n - 1);
+                const bool alive = ra < FC_H, blive = wb < n;
+                f32x16q acc;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wpi[i] = min(wp0 + 8 * i, n - 1);
-            for (int w = 0; w < n; ++w) {
-                const double v = (double)v1[w];
-                const float* crow = Cs + w * n;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) t[i] = fma(v, (double)crow[wpi[i]], t[i]);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (wp0 + 8 * i < n) {
-                    var = fma(t[i], (double)v1[wpi[i]], var);
-                    // V1.C is also what the backward needs (hq in the mid kernels): keep it
-                    if (r < FC_H) VC[((size_t)u * FC_H + r) * NS + wpi[i]] = (float)t[i];
+                for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+                for (int s2 = 0; s2 < (n + 1) / 2; ++s2) {
+                    const int w = 2 * s2 + kk, wc = min(w, n - 1);
+                    const float a = (alive && w < n) ? arow[wc] : 0.f;
+                    const float b = (blive && w < n) ? bcol[wc * n] : 0.f;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
                 }
+                if (blive) {
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) {
+                        const int ro = 32 * t + (g & 3) + 8 * (g >> 2) + 4 * kk;
+                        if (ro < FC_H) VC[((size_t)u * FC_H + ro) * NS + wb] = acc[g];
+                    }
+                }
+            }
+            __syncthreads();                  // this block's VC writes are visible to its own reads
+            for (int wp = part; wp < n; wp += 8)
+                var = fma((double)VC[((size_t)u * FC_H + rr) * NS + wp], (double)v1[wp], var);
+        } else {
+            // four columns w' per pass: independent fma chains instead of one 26..160-long chain
+            for (int wp0 = part; wp0 < n; wp0 += 32) {
+                int wpi[4];
+                double t[4] = {0, 0, 0, 0};
+    #pragma unroll
+                for (int i = 0; i < 4; ++i) wpi[i] = min(wp0 + 8 * i, n - 1);
+                for (int w = 0; w < n; ++w) {
+                    const double v = (double)v1[w];
+                    const float* crow = Cs + w * n;
+    #pragma unroll
+                    for (int i = 0; i < 4; ++i) t[i] = fma(v, (double)crow[wpi[i]], t[i]);
+                }
+    #pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (wp0 + 8 * i < n) {
+                        var = fma(t[i], (double)v1[wpi[i]], var);
+                        // V1.C is also what the backward needs (hq in the mid kernels): keep it
+                        if (r < FC_H) VC[((size_t)u * FC_H + r) * NS + wpi[i]] = (float)t[i];
+                    }
+            }
         }
         var += __shfl_xor(var, 1, 64); var += __shfl_xor(var, 2, 64); var += __shfl_xor(var, 4, 64);
         const int ch = u * FC_H + rr;
@@ -480,12 +514,12 @@ int launch_prep2(explainn_ctx* c, const explainn_params* p, int B, bool train, h
     if (train)
         hipLaunchKernelGGL(prep2_kernel<true>, dim3(c->U), dim3(1024), prep2_lds(c->n, c->NS), s,
                            p->fc1_w, p->fc1_b, p->bn2_w, p->bn2_b, p->bn2_rm, p->bn2_rv, p->bn2_nbt,
-                           c->qs0, c->qS1p, c->qS2p, c->qbar, c->C, c->VC, c->A2, c->A2f, c->sh2, c->sig2,
+                           c->qs0, c->qS1p, c->qS2p, c->qbar, c->VC, c->A2, c->A2f, c->sh2, c->sig2,
                            c->n, c->NS, (c->NQ + 1) / 2, B, c->QCH);
     else
         hipLaunchKernelGGL(prep2_kernel<false>, dim3(c->U), dim3(1024), 0, s, p->fc1_w, p->fc1_b,
                            p->bn2_w, p->bn2_b, p->bn2_rm, p->bn2_rv, (int64_t*)nullptr, c->qs0,
-                           c->qS1p, c->qS2p, c->qbar, c->C, c->VC, c->A2, c->A2f, c->sh2, c->sig2, c->n,
+                           c->qS1p, c->qS2p, c->qbar, c->VC, c->A2, c->A2f, c->sh2, c->sig2, c->n,
                            c->NS, (c->NQ + 1) / 2, B, c->QCH);
     LAUNCH_CHECK();
     return EXPLAINN_OK;

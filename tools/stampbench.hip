@@ -78,7 +78,7 @@ int main() {
         float* lut = (float*)dalloc((size_t)(U4 / 2) * NT * 32 * 4); float* Wt = (float*)dalloc((size_t)(U4 / 4) * k * 20 * 4);
         uint8_t* idx = (uint8_t*)dalloc((size_t)U * n * Bs);
         float* Dspp = (float*)dalloc((size_t)U * (Bs / 64) * 76 * 4);
-        float* fc1_w = (float*)dalloc((size_t)U * 100 * n * 4); float* C = (float*)dalloc((size_t)U * NS * NS * 4);
+        float* fc1_w = (float*)dalloc((size_t)U * 100 * n * 4); float* VC = (float*)dalloc((size_t)U * 100 * NS * 4);
         double* qbar = (double*)dalloc((size_t)U * NS * 8); float* A2 = (float*)dalloc((size_t)U * 100 * NS * 4);
         float* sig2 = (float*)dalloc(U * 100 * 4); std::vector<float> ones(U * 100, 1.f); CK(hipMemcpy(sig2, ones.data(), U * 100 * 4, hipMemcpyHostToDevice));
         float* md = (float*)dalloc((size_t)U * 100 * n * 4 + 4096);
@@ -93,11 +93,11 @@ int main() {
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
             if (rep) report("conv_bwd", 16 * U, 4, ms);
             CK(hipEventRecord(e0));
-            hipLaunchKernelGGL(prep2_kernel<true>, dim3(U), dim3(1024), prep2_lds(n, NS), 0, fc1_w, sh2, sh2, sh2, md, md + U * 100, (int64_t*)nullptr, qs0, S1p, S2p, qbar, C, A2, A2f, sh2, sig2, n, NS, NKS, B, QCH);
+            hipLaunchKernelGGL(prep2_kernel<true>, dim3(U), dim3(1024), prep2_lds(n, NS), 0, fc1_w, sh2, sh2, sh2, md, md + U * 100, (int64_t*)nullptr, qs0, S1p, S2p, qbar, VC, A2, A2f, sh2, sig2, n, NS, NKS, B, QCH);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
             if (rep) report("prep2", U * 16, 4, ms);
             CK(hipEventRecord(e0));
-            hipLaunchKernelGGL(mid_fused_kernel, dim3(U), dim3(1024), mid_fused_lds(n), 0, EQp, Sep, A2, sh2, sig2, fc1_w, V2, sh2, qbar, C, Tt, Tt, M, M, k0p, md, md, md, md, md, n, NS, 1, 13, B, ACH, 1.4285715f);
+            hipLaunchKernelGGL(mid_fused_kernel, dim3(U), dim3(1024), mid_fused_lds(n), 0, EQp, Sep, A2, sh2, sig2, fc1_w, V2, sh2, qbar, VC, Tt, Tt, M, M, k0p, md, md, md, md, md, n, NS, 1, 13, B, ACH, 1.4285715f);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
             if (rep) report("mid_fused", U * 16, 6, ms);
         }
