@@ -43,7 +43,7 @@ EXPORTS = (
     "explainn_create", "explainn_destroy", "explainn_last_error", "explainn_scratch_bytes",
     "explainn_forward_eval", "explainn_forward_train", "explainn_backward", "explainn_loss_grad",
     "explainn_train_step", "explainn_unit_outputs", "explainn_unit_activations",
-    "explainn_input_flags",
+    "explainn_input_flags", "explainn_filter_act_max", "explainn_filter_sites",
 )
 
 
@@ -97,6 +97,10 @@ def load():
     lib.explainn_unit_outputs.restype = C.c_int
     lib.explainn_unit_activations.argtypes = [ctx, _fp, C.c_int, pp, _fp, _fp]
     lib.explainn_unit_activations.restype = C.c_int
+    lib.explainn_filter_act_max.argtypes = [ctx, _fp, C.c_int, pp, _fp, _fp, _fp]
+    lib.explainn_filter_act_max.restype = C.c_int
+    lib.explainn_filter_sites.argtypes = [ctx, _fp, C.c_int, pp, _fp, _fp, C.c_int, _fp, _fp, _fp, _fp]
+    lib.explainn_filter_sites.restype = C.c_int
     lib.explainn_input_flags.argtypes = [ctx, C.POINTER(C.c_int), _fp]
     lib.explainn_input_flags.restype = C.c_int
     _lib = lib

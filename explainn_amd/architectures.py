@@ -411,6 +411,59 @@ class ExplaiNN(_Model):
         return acts
 
 
+    # -- filter -> PWM export (interpret.py:363-459 on the device; see explainn_amd/interpret.py) --
+    def _export_args(self, x, select):
+        if self.training:
+            raise NotImplementedError("the filter export runs in eval mode; call model.eval()")
+        dev = self._device()
+        x = self._prep_input(x, dev)
+        B = x.shape[0]
+        if select is not None:
+            if select.shape != (B,) or select.device != dev:
+                raise RuntimeError("select must be a (B,) tensor on the model's device")
+            select = select.to(torch.uint8).contiguous()
+        return dev, x, B, select
+
+    def filter_act_max(self, x, unit_max, select=None):
+        """unit_max[u] (float32 [U], zeroed by the caller before the first batch) <- running max of
+        the float16-rounded eval-mode activations of the selected sequences of this batch."""
+        dev, x, B, select = self._export_args(x, select)
+        ctx = self._context(B, dev)
+        ps, keep = self._params_struct(dev)
+        with torch.cuda.device(dev):
+            _lib.check(ctx.lib.explainn_filter_act_max(
+                ctx.handle, x.data_ptr(), B, C.byref(ps),
+                select.data_ptr() if select is not None else None, unit_max.data_ptr(),
+                self._stream(dev)))
+            self._check_flags(ctx, dev)
+        return unit_max
+
+    def filter_sites(self, x, thresholds, site_total, pfm, select=None, site_cap=1000000,
+                     want_hit=False):
+        """Accumulate this batch's sites into pfm (int32 (U,k,4)) / site_total (int32 [U]); returns
+        the (B,U) uint8 "has a site" matrix when want_hit."""
+        dev, x, B, select = self._export_args(x, select)
+        o = self._options
+        U, k = o["cnn_units"], o["kernel_size"]
+        for name, t, shape, dt in (("thresholds", thresholds, (U,), torch.float32),
+                                   ("site_total", site_total, (U,), torch.int32),
+                                   ("pfm", pfm, (U, k, 4), torch.int32)):
+            if tuple(t.shape) != shape or t.dtype != dt or t.device != dev or not t.is_contiguous():
+                raise RuntimeError("%s must be a contiguous %s tensor of shape %s on %s" % (
+                    name, dt, shape, dev))
+        ctx = self._context(B, dev)
+        ps, keep = self._params_struct(dev)
+        hit = torch.empty(B, U, device=dev, dtype=torch.uint8) if want_hit else None
+        with torch.cuda.device(dev):
+            _lib.check(ctx.lib.explainn_filter_sites(
+                ctx.handle, x.data_ptr(), B, C.byref(ps),
+                select.data_ptr() if select is not None else None, thresholds.data_ptr(),
+                int(site_cap), site_total.data_ptr(), pfm.data_ptr(),
+                hit.data_ptr() if hit is not None else None, self._stream(dev)))
+            self._check_flags(ctx, dev)
+        return hit
+
+
 # ----------------------------------------------------------------------------------------------
 def get_loss(input_data="binary"):
     """architectures/__init__.py:446-456."""

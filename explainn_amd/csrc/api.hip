@@ -78,6 +78,8 @@ void carve(explainn_ctx* c, Carver& cv) {
     cv.take(&c->Dspp, U * (Bs / 64) * K4);
     cv.take(&c->dlogits, (int64_t)c->maxB * c->T);
     cv.take(&c->flags, 64);
+    cv.take(&c->site_cnt, U4 * Bs);
+    cv.take(&c->site_off, U4 * Bs);
     cv.off = (cv.off + 255) & ~int64_t(255);
 }
 
@@ -229,6 +231,30 @@ extern "C" int explainn_unit_activations(explainn_ctx* c, const float* x, int B,
     TRY(eval_front(c, x, B, p, s));
     TRY(launch_conv_act(c, B, acts, s));
     return EXPLAINN_OK;
+}
+
+extern "C" int explainn_filter_act_max(explainn_ctx* c, const float* x, int B,
+                                       const explainn_params* p, const uint8_t* select,
+                                       float* unit_max, void* stream) {
+    TRY(check_batch(c, B));
+    if (!unit_max) { explainn_set_error("unit_max is null"); return EXPLAINN_E_ARG; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    TRY(eval_front(c, x, B, p, s));
+    return launch_filter_act_max(c, B, select, unit_max, s);
+}
+
+extern "C" int explainn_filter_sites(explainn_ctx* c, const float* x, int B, const explainn_params* p,
+                                     const uint8_t* select, const float* thresholds, int site_cap,
+                                     int32_t* site_total, int32_t* pfm, uint8_t* hit, void* stream) {
+    TRY(check_batch(c, B));
+    if (!thresholds || !site_total || !pfm) {
+        explainn_set_error("thresholds, site_total and pfm are required");
+        return EXPLAINN_E_ARG;
+    }
+    if (site_cap <= 0) { explainn_set_error("site_cap must be positive"); return EXPLAINN_E_ARG; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    TRY(eval_front(c, x, B, p, s));
+    return launch_filter_sites(c, B, select, thresholds, site_cap, site_total, pfm, hit, s);
 }
 
 extern "C" int explainn_forward_train(explainn_ctx* c, const float* x, int B,

@@ -80,6 +80,8 @@ struct explainn_ctx {
     float* Dspp;          // [U][Bs/64][4k]
     float* dlogits;       // [maxB][T]         (train_step only)
     int* flags;           // [1]
+    int* site_cnt;        // [U4][Bs]  sites per (unit, sequence) of the current batch (filter->PWM export)
+    int* site_off;        // [U4][Bs]  their exclusive scan in sequence order, plus the running total
 };
 
 // ---- error plumbing (api.hip) ----
@@ -102,6 +104,9 @@ int launch_moments(explainn_ctx* c, int B, hipStream_t s);
 int launch_prep1_tables(explainn_ctx* c, const explainn_params* p, hipStream_t s);
 int launch_conv_pool(explainn_ctx* c, const explainn_params* p, int B, hipStream_t s);
 int launch_conv_act(explainn_ctx* c, int B, float* acts, hipStream_t s);
+int launch_filter_act_max(explainn_ctx* c, int B, const uint8_t* select, float* umax, hipStream_t s);
+int launch_filter_sites(explainn_ctx* c, int B, const uint8_t* select, const float* thr, int cap,
+                        int* site_total, int* pfm, uint8_t* hit, hipStream_t s);
 int launch_qmoments(explainn_ctx* c, int B, hipStream_t s);
 int launch_prep2(explainn_ctx* c, const explainn_params* p, int B, bool train, hipStream_t s);
 int launch_fc_fwd(explainn_ctx* c, const explainn_params* p, int B, bool train,

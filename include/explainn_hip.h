@@ -126,6 +126,30 @@ int explainn_unit_outputs(explainn_ctx* ctx, const float* x, int B, const explai
 int explainn_unit_activations(explainn_ctx* ctx, const float* x, int B, const explainn_params* p,
                               float* acts, void* stream);
 
+/* Filter -> PWM export, replacing the dense float16 (N,U,Lo) host array of
+ * test.py:128-166 and the Python loops of interpret.py:363-459.  Both calls stream batches; the
+ * accumulators live in caller memory (device pointers) and persist across calls.
+ *
+ * select: [B] bytes or NULL -- 1 = the sequence is one of the "well predicted" ones
+ * (interpret.py:310-361, host logic); unselected sequences contribute nothing.
+ *
+ * explainn_filter_act_max: unit_max[u] = max(unit_max[u], max over selected sequences and positions
+ * of the eval-mode activation rounded to float16 as test.py:137 stores it).  Zero unit_max before
+ * the first batch; interpret.py:373's threshold is 0.5 * unit_max (in float16). */
+int explainn_filter_act_max(explainn_ctx* ctx, const float* x, int B, const explainn_params* p,
+                            const uint8_t* select, float* unit_max, void* stream);
+/* explainn_filter_sites: every start position j of a selected sequence whose float16 activation
+ * exceeds thresholds[u] is a site x[j : j+k] (interpret.py:401-421); pfm[u][t][a] (int32, (U,k,4),
+ * A/C/G/T; an N inside a site counts for no letter) += its letters (interpret.py:431-459).  Sites
+ * are ranked in (call, sequence, position) order -- feed the forward strand's batches first, then the
+ * reverse strand's, as interpret.py:385-429 iterates -- and only the first site_cap per unit count
+ * (interpret.py:423-425, 1e6 there); site_total[u] (int32 [U], zero before the first batch) carries
+ * the rank across calls and ends as min(#sites, site_cap).  hit: optional (B,U) bytes out, 1 = the
+ * sequence has at least one position above the unit's threshold (interpret.py:485-490). */
+int explainn_filter_sites(explainn_ctx* ctx, const float* x, int B, const explainn_params* p,
+                          const uint8_t* select, const float* thresholds, int site_cap,
+                          int32_t* site_total, int32_t* pfm, uint8_t* hit, void* stream);
+
 /* Input validation result of every pack since the last call: bit 0 set = some column of x was
  * neither one-hot nor all-zero (such columns were treated as N).  Synchronises `stream`,
  * writes the flags to *flags_host and clears them. */

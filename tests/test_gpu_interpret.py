@@ -1,0 +1,121 @@
+"""GPU: the device-side filter -> PWM export (csrc/interpret.hip through the C ABI and
+explainn_amd/interpret.py) against the reference-fed fixtures, and -- at the C2 shape, streamed in
+several batches -- against a dense numpy recount of the product's own float16 activations."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from test_interpret_oracle import PFM_CASES, load, onehot  # noqa: E402
+from oracle import interpret_oracle as io  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(z, m):
+    from explainn_amd import ExplaiNN
+    net = ExplaiNN(m["U"], m["k"], m["L"], m["T"])
+    net.load_state_dict({k[3:]: torch.from_numpy(np.array(z[k])) for k in z.files if k.startswith("sd/")})
+    return net.cuda().eval()
+
+
+@pytest.mark.parametrize("name", PFM_CASES)
+@pytest.mark.parametrize("batch", [1024, 7])
+def test_filter_pwms_golden(name, batch):
+    from explainn_amd import interpret as it
+    z, m = load(name)
+    net = _model(z, m)
+    x = onehot(z["codes"])
+    outs, preds = it._get_outs_preds(net, x, batch_size=16)
+    for mine, ref in ((outs, z["outs"]), (preds, z["preds"])):
+        ulp = np.maximum(np.abs(ref.astype(np.float64)), 2.0 ** -14) * 2.0 ** -10
+        assert (np.abs(mine.astype(np.float64) - ref.astype(np.float64)) <= ulp).all()
+    idxs = z["idxs"]
+    res = it.filter_pwms(net, x, idxs, m["rc"], batch_size=batch, site_cap=m["cap"])
+    assert res["thresholds"].dtype == np.float16
+    assert np.array_equal(res["thresholds"], z["thresholds"]), (res["thresholds"], z["thresholds"])
+    assert np.array_equal(res["nsites"], z["nsites"]), (res["nsites"], z["nsites"])
+    assert np.array_equal(res["pfm"], z["pfm"])
+    hit_ref = (z["acts"] > z["thresholds"][None, :, None]).any(axis=2)
+    sel = np.zeros(len(x), dtype=bool)
+    sel[idxs] = True
+    if m["rc"]:
+        sel[idxs + len(x) // 2] = True
+    assert np.array_equal(res["hit"][sel], hit_ref[sel])
+    assert not res["hit"][~sel].any()
+    for u, (s_u, imps) in enumerate(it.filter_importances(z["outs"], z["sd/final.weight"], idxs, res["hit"])):
+        assert np.array_equal(s_u, z["imp_sel/%d" % u])
+        assert np.array_equal(imps, z["imp/%d" % u])
+
+
+def test_dense_export_matches_reference_float16():
+    from explainn_amd import interpret as it
+    from torch.utils.data import DataLoader, TensorDataset
+    z, m = load("pfm_u8_k9")
+    net = _model(z, m)
+    x = torch.from_numpy(onehot(z["codes"]))
+    loader = DataLoader(TensorDataset(x, torch.zeros(len(x), 1)), batch_size=20)
+    acts, outs, preds = it._get_acts_outs_preds(net, loader)
+    assert acts.dtype == np.float16 and acts.shape == z["acts"].shape
+    assert (acts == z["acts"]).mean() > 0.995
+    ulp = np.maximum(np.abs(z["acts"].astype(np.float64)), 2.0 ** -14) * 2.0 ** -10
+    assert (np.abs(acts.astype(np.float64) - z["acts"].astype(np.float64)) <= ulp).all()
+
+
+def _dense_recount(acts16, codes, sel_idx, k, cap):
+    """numpy recount from a dense float16 activation array, first `cap` sites per unit in
+    (sequence, position) order."""
+    N, U, Lo = acts16.shape
+    thr = 0.5 * np.amax(acts16[sel_idx], axis=(0, 2))
+    pfm = np.zeros((U, k, 4), dtype=np.int64)
+    nsites = np.zeros(U, dtype=np.int64)
+    for u in range(U):
+        ii, jj = np.where(acts16[sel_idx, u, :] > thr[u])
+        ii, jj = ii[:cap], jj[:cap]
+        nsites[u] = len(ii)
+        if len(ii) == 0:
+            continue
+        sites = codes[sel_idx[ii][:, None], jj[:, None] + np.arange(k)[None, :]]     # (S,k)
+        for a in range(4):
+            pfm[u, :, a] = (sites == a).sum(axis=0)
+    return thr, pfm, nsites
+
+
+@pytest.mark.parametrize("cap", [io.SITE_CAP, 300])
+def test_c2_shape_streamed_against_dense_recount(cap):
+    """300 units, 200 bp, 700 sequences in batches of 256 (ragged tail), 1 % N, every third
+    sequence selected.  The device export must equal a recount from the dense float16 activations
+    the same model produces through model.linears[:3] (the reference's own data flow)."""
+    from explainn_amd import ExplaiNN, interpret as it
+    torch.manual_seed(5)
+    U, k, L, N = 300, 19, 200, 700
+    net = ExplaiNN(U, k, L, 1).cuda().eval()
+    g = np.random.default_rng(9)
+    codes = g.integers(0, 4, size=(N, L)).astype(np.uint8)
+    codes[g.random((N, L)) < 0.01] = 4
+    x = onehot(codes)
+    idxs = np.arange(0, N, 3)
+    acts = np.zeros((N, U, L - k + 1), dtype=np.float16)
+    with torch.no_grad():
+        for i in range(0, N, 100):
+            acts[i:i + 100] = net.linears[:3](torch.from_numpy(x[i:i + 100]).cuda()).cpu().numpy()
+    thr, pfm, nsites = _dense_recount(acts, codes, idxs, k, cap)
+    res = it.filter_pwms(net, x, idxs, False, batch_size=256, site_cap=cap)
+    assert np.array_equal(res["thresholds"], thr)
+    assert np.array_equal(res["nsites"], nsites)
+    assert np.array_equal(res["pfm"], pfm)
+    if cap < io.SITE_CAP:
+        assert nsites.max() == cap
+
+
+def test_export_needs_eval_mode_and_checks_shapes():
+    from explainn_amd import ExplaiNN
+    net = ExplaiNN(4, 5, 30, 1).cuda()
+    x = torch.zeros(3, 4, 30).cuda()
+    x[:, 0, :] = 1
+    with pytest.raises(NotImplementedError):
+        net.train().filter_act_max(x, torch.zeros(4).cuda())
+    net.eval()
+    with pytest.raises(RuntimeError):
+        net.filter_sites(x, torch.zeros(3).cuda(), torch.zeros(4, dtype=torch.int32).cuda(),
+                         torch.zeros(4, 5, 4, dtype=torch.int32).cuda())

@@ -246,11 +246,88 @@ def make_encoding_case():
     print("encoding")
 
 
+def make_pfm_case(name, U, k, L, T, N, seed, rev_complement, loss_kind="binary", n_frac=0.0, cap=None):
+    """Filter -> PWM fixture.  The float16 activations / unit outputs / predictions
+    come from the imported reference model exactly as test.py:128-166 extracts them (x.repeat ->
+    model.linears, model.final, model.linears[:3]); the bookkeeping after that (well-predicted
+    selection, thresholds, site counting, importances) has no importable form here -- interpret.py
+    compiles a C tool into the reference tree at import time -- so it is oracle/interpret_oracle.py's
+    restatement applied to those reference activations."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from oracle import interpret_oracle as io
+    torch.manual_seed(seed)
+    model = ExplaiNN(U, k, L, T)
+    perturb_bn(model, seed + 1, False)
+    model.eval()
+    codes = make_codes(N, L, seed + 2, n_frac)
+    # plant a motif in half of the sequences so that some filters see repeated strong sites
+    g = np.random.default_rng(seed + 3)
+    motif = g.integers(0, 4, size=k).astype(np.uint8)
+    for i in range(0, N, 2):
+        s0 = int(g.integers(0, L - k + 1))
+        codes[i, s0:s0 + k] = motif
+    x = codes_to_onehot(codes)
+    if loss_kind == "binary":
+        labels = (g.random((N, T)) > 0.5).astype(np.float64)
+    else:
+        labels = g.standard_normal((N, T))
+    if rev_complement:
+        x = np.append(x, ref_sequence.rc_one_hot_encoding_many(x), axis=0)
+        labels = np.append(labels, labels, axis=0)
+        rc_codes = (3 - codes[:, ::-1]).astype(np.int16)
+        rc_codes[codes[:, ::-1] == 4] = 4
+        codes = np.append(codes, rc_codes.astype(np.uint8), axis=0)
+    Lo = L - k + 1
+    acts = np.zeros((len(x), U, Lo), dtype=np.float16)
+    outs = np.zeros((len(x), U), dtype=np.float16)
+    preds = np.zeros((len(x), T), dtype=np.float16)
+    with torch.no_grad():
+        bs = 16
+        for i0 in range(0, len(x), bs):
+            Xs = torch.Tensor(x[i0:i0 + bs]).repeat(1, U, 1)
+            o = model.linears(Xs)
+            outs[i0:i0 + bs] = o.numpy()
+            preds[i0:i0 + bs] = model.final(o).numpy()
+            acts[i0:i0 + bs] = model.linears[:3](Xs).numpy()
+    if loss_kind != "binary":
+        # a regression target that the (random) model "predicts": prediction + noise, so that the
+        # top-5% intersection of interpret.py:345-359 is not empty
+        labels = preds.astype(np.float64) + 0.05 * g.standard_normal(preds.shape)
+    # selection with the reference's own torch expression where one is used (interpret.py:326,330)
+    idxs = io.well_predicted_sequences(preds, labels, loss_kind, rev_complement)
+    if loss_kind == "binary" and not rev_complement:
+        p = torch.sigmoid(torch.from_numpy(preds)).numpy()
+        ref_idxs = np.where((labels == (p > .5).astype(int)).all(axis=1))[0]
+        assert np.array_equal(idxs, ref_idxs)
+    thr = io.act_thresholds(acts, idxs, rev_complement)
+    kw = {} if cap is None else {"cap": cap}
+    pfm, nsites = io.site_pfms(codes, acts, idxs, thr, k, rev_complement, **kw)
+    imps = io.filter_importances(outs, model.final.weight.detach().numpy(), idxs, acts, thr)
+    out = sd_np(model)
+    out.update({"codes": codes, "labels": labels, "acts": acts, "outs": outs, "preds": preds,
+                "idxs": idxs, "thresholds": thr, "pfm": pfm, "nsites": nsites,
+                "meta": np.array([U, k, L, T, len(x), int(rev_complement),
+                                  0 if loss_kind == "binary" else 1,
+                                  io.SITE_CAP if cap is None else cap], dtype=np.int64)})
+    for u, (sel, im) in enumerate(imps):
+        out["imp_sel/%d" % u] = sel
+        out["imp/%d" % u] = im
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "selected", len(idxs), "sites", nsites.tolist())
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     make_encoding_case()
     if len(sys.argv) > 1 and sys.argv[1] == "trainer":
         make_trainer_case()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "pfm":
+        #             name              U   k   L  T   N seed  rc
+        make_pfm_case("pfm_u8_k9",      8,  9, 60, 1, 48, 30, False)
+        make_pfm_case("pfm_u8_k9_rc",   8,  9, 60, 2, 48, 31, True, n_frac=0.02)
+        make_pfm_case("pfm_u6_k19_cap", 6, 19, 80, 1, 40, 32, False, cap=25)
+        make_pfm_case("pfm_u5_k7_lin",  5,  7, 50, 1, 120, 33, False, loss_kind="linear")
         sys.exit(0)
     #          name               U   k   L   T   B  seed
     make_case("tiny_u1_k5",       1,  5,  26, 1,  2, 10)
