@@ -5,6 +5,6 @@ the `Trainer` step loop (explainn/selene/__init__.py) and the `train._train` / `
 points.  The compute lives in `libexplainn_hip.so` (hand-written HIP for gfx950, C ABI in
 include/explainn_hip.h); importing this package never falls back to a CPU implementation.
 """
-from .architectures import ExplaiNN, get_loss, get_metrics, get_optimizer  # noqa: F401
+from .architectures import ExplaiNN, PWM, get_loss, get_metrics, get_optimizer  # noqa: F401
 
-__all__ = ["ExplaiNN", "get_loss", "get_metrics", "get_optimizer"]
+__all__ = ["ExplaiNN", "PWM", "get_loss", "get_metrics", "get_optimizer"]

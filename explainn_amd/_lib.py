@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("EXPLAINN_HIP_LIB", os.path.join(_HERE, "libexplainn_h
 
 OK, E_ARG, E_HIP, E_BATCH1, E_STATE, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 LOSS_BCE_WITH_LOGITS, LOSS_MSE = 0, 1
+PWM_SUM, PWM_MAX = 0, 1
 
 _fp = C.c_void_p          # device pointers travel as integers (tensor.data_ptr())
 
@@ -44,6 +45,7 @@ EXPORTS = (
     "explainn_forward_eval", "explainn_forward_train", "explainn_backward", "explainn_loss_grad",
     "explainn_train_step", "explainn_unit_outputs", "explainn_unit_activations",
     "explainn_input_flags", "explainn_filter_act_max", "explainn_filter_sites",
+    "explainn_pwm_scan", "explainn_stage_codes",
 )
 
 
@@ -101,6 +103,10 @@ def load():
     lib.explainn_filter_act_max.restype = C.c_int
     lib.explainn_filter_sites.argtypes = [ctx, _fp, C.c_int, pp, _fp, _fp, C.c_int, _fp, _fp, _fp, _fp]
     lib.explainn_filter_sites.restype = C.c_int
+    lib.explainn_stage_codes.argtypes = [ctx, _fp, C.c_int, C.c_int, _fp]
+    lib.explainn_stage_codes.restype = C.c_int
+    lib.explainn_pwm_scan.argtypes = [_fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp]
+    lib.explainn_pwm_scan.restype = C.c_int
     lib.explainn_input_flags.argtypes = [ctx, C.POINTER(C.c_int), _fp]
     lib.explainn_input_flags.restype = C.c_int
     _lib = lib

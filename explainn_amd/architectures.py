@@ -20,6 +20,7 @@ import math
 import weakref
 from collections import OrderedDict
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -113,6 +114,22 @@ class _UnitStack(nn.Sequential):
                 return _UnitPrefix(self._owner())
             raise NotImplementedError("only linears[:3] (conv+BN+exp) is exposed as a sub-stack")
         return super().__getitem__(idx)
+
+
+class BaseCodes:
+    """A batch handed over as base codes instead of an fp32 one-hot: `codes` is a
+    (B,L) uint8 tensor on the model's device, 0..3 = A,C,G,T, 4 = N (sequence.encode_codes_many);
+    reverse_complement=True makes the kernel read it as its reverse complement, so the strand
+    augmentation of train.py:275-278 / predict.py:78-79 needs no second copy.  Accepted wherever
+    the model takes `x`; a bare uint8 (B,L) tensor means BaseCodes(codes, False)."""
+
+    def __init__(self, codes, reverse_complement=False):
+        self.codes = codes
+        self.reverse_complement = bool(reverse_complement)
+
+    @property
+    def shape(self):
+        return self.codes.shape
 
 
 class _Runtime:
@@ -266,12 +283,30 @@ class ExplaiNN(_Model):
 
     def _prep_input(self, x, dev):
         o = self._options
+        if isinstance(x, BaseCodes) or (torch.is_tensor(x) and x.dtype == torch.uint8 and x.dim() == 2):
+            bc = x if isinstance(x, BaseCodes) else BaseCodes(x)
+            c = bc.codes
+            if not torch.is_tensor(c) or c.dtype != torch.uint8 or c.dim() != 2 or \
+                    c.shape[1] != o["sequence_length"]:
+                raise RuntimeError("base codes must be a uint8 tensor of shape (B, %d)" % o["sequence_length"])
+            if c.device != dev:
+                raise RuntimeError("input is on %s but the model is on %s" % (c.device, dev))
+            return BaseCodes(c.detach().contiguous(), bc.reverse_complement)
         if x.dim() != 3 or x.shape[1] != 4 or x.shape[2] != o["sequence_length"]:
             raise RuntimeError("expected input of shape (B, 4, %d), got %s" % (
                 o["sequence_length"], tuple(x.shape)))
         if x.device != dev:
             raise RuntimeError("input is on %s but the model is on %s" % (x.device, dev))
         return x.detach().to(torch.float32).contiguous()
+
+    def _x_ptr(self, ctx, x, dev):
+        """Device pointer of the one-hot batch, or -- for base codes -- stage them in the context
+        and return NULL ("the staged batch", include/explainn_hip.h)."""
+        if isinstance(x, BaseCodes):
+            _lib.check(ctx.lib.explainn_stage_codes(ctx.handle, x.codes.data_ptr(), x.codes.shape[0],
+                                                    int(x.reverse_complement), self._stream(dev)))
+            return None
+        return x.data_ptr()
 
     def _stream(self, dev):
         return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
@@ -310,7 +345,7 @@ class ExplaiNN(_Model):
         ps, keep = self._params_struct(dev)
         logits = torch.empty(B, self._options["n_features"], device=dev, dtype=torch.float32)
         with torch.cuda.device(dev):
-            _lib.check(ctx.lib.explainn_forward_eval(ctx.handle, x.data_ptr(), B, C.byref(ps),
+            _lib.check(ctx.lib.explainn_forward_eval(ctx.handle, self._x_ptr(ctx, x, dev), B, C.byref(ps),
                                                      logits.data_ptr(), self._stream(dev)))
             self._check_flags(ctx, dev)
         return logits
@@ -333,7 +368,7 @@ class ExplaiNN(_Model):
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if self.dropout_p > 0 else 0
         with torch.cuda.device(dev):
             _lib.check(ctx.lib.explainn_forward_train(
-                ctx.handle, x.data_ptr(), B, C.byref(ps), mask_ptr, float(self.dropout_p),
+                ctx.handle, self._x_ptr(ctx, x, dev), B, C.byref(ps), mask_ptr, float(self.dropout_p),
                 C.c_uint64(seed), logits.data_ptr(), self._stream(dev)))
             self._check_flags(ctx, dev)
         self._rt.token += 1
@@ -372,6 +407,8 @@ class ExplaiNN(_Model):
     # -- the façade test.py / interpret.py use -----------------------------------------------
     def _first_four_rows(self, x_rep):
         U = self._options["cnn_units"]
+        if isinstance(x_rep, BaseCodes) or (torch.is_tensor(x_rep) and x_rep.dtype == torch.uint8):
+            return x_rep
         if x_rep.dim() != 3 or x_rep.shape[1] not in (4, 4 * U):
             raise RuntimeError("expected the repeated input (B, 4*cnn_units, L) or (B, 4, L)")
         return x_rep[:, :4, :]
@@ -387,7 +424,7 @@ class ExplaiNN(_Model):
         ps, keep = self._params_struct(dev)
         outs = torch.empty(B, self._options["cnn_units"], device=dev, dtype=torch.float32)
         with torch.cuda.device(dev):
-            _lib.check(ctx.lib.explainn_unit_outputs(ctx.handle, x.data_ptr(), B, C.byref(ps),
+            _lib.check(ctx.lib.explainn_unit_outputs(ctx.handle, self._x_ptr(ctx, x, dev), B, C.byref(ps),
                                                      outs.data_ptr(), self._stream(dev)))
             self._check_flags(ctx, dev)
         return outs
@@ -405,7 +442,7 @@ class ExplaiNN(_Model):
         acts = torch.empty(B, o["cnn_units"], o["sequence_length"] - o["kernel_size"] + 1,
                            device=dev, dtype=torch.float32)
         with torch.cuda.device(dev):
-            _lib.check(ctx.lib.explainn_unit_activations(ctx.handle, x.data_ptr(), B, C.byref(ps),
+            _lib.check(ctx.lib.explainn_unit_activations(ctx.handle, self._x_ptr(ctx, x, dev), B, C.byref(ps),
                                                          acts.data_ptr(), self._stream(dev)))
             self._check_flags(ctx, dev)
         return acts
@@ -432,7 +469,7 @@ class ExplaiNN(_Model):
         ps, keep = self._params_struct(dev)
         with torch.cuda.device(dev):
             _lib.check(ctx.lib.explainn_filter_act_max(
-                ctx.handle, x.data_ptr(), B, C.byref(ps),
+                ctx.handle, self._x_ptr(ctx, x, dev), B, C.byref(ps),
                 select.data_ptr() if select is not None else None, unit_max.data_ptr(),
                 self._stream(dev)))
             self._check_flags(ctx, dev)
@@ -456,12 +493,53 @@ class ExplaiNN(_Model):
         hit = torch.empty(B, U, device=dev, dtype=torch.uint8) if want_hit else None
         with torch.cuda.device(dev):
             _lib.check(ctx.lib.explainn_filter_sites(
-                ctx.handle, x.data_ptr(), B, C.byref(ps),
+                ctx.handle, self._x_ptr(ctx, x, dev), B, C.byref(ps),
                 select.data_ptr() if select is not None else None, thresholds.data_ptr(),
                 int(site_cap), site_total.data_ptr(), pfm.data_ptr(),
                 hit.data_ptr() if hit is not None else None, self._stream(dev)))
             self._check_flags(ctx, dev)
         return hit
+
+
+class PWM(nn.Module):
+    """Frozen position-weight-matrix scanner, the reference's `PWM` (architectures/__init__.py:
+    116-170): `pwms` (G,4,k) in ACGT row order, both strands, per-sequence max or sum of the window
+    scores -> (B,G).  `conv1d.weight` / `conv1d.bias` keep the reference's state_dict layout; the
+    scan itself is one HIP launch (csrc/pwm.hip), there is no CPU fallback."""
+
+    def __init__(self, pwms, sequence_length, scoring="sum"):
+        super().__init__()
+        pwms = np.asarray(pwms, dtype=np.float32)
+        groups, four, kernel_size = pwms.shape
+        if four != 4:
+            raise ValueError("pwms must have shape (n, 4, length)")
+        self._options = {"groups": groups, "kernel_size": kernel_size,
+                         "sequence_length": sequence_length, "scoring": scoring}
+        self.conv1d = _GroupedTaps(groups, 4, kernel_size)
+        self.conv1d.weight.data = torch.from_numpy(pwms.copy())
+        self.conv1d.bias.data = torch.zeros(groups)
+        for p in self.conv1d.parameters():
+            p.requires_grad = False
+
+    def forward(self, x):
+        o = self._options
+        w = self.conv1d.weight
+        if w.device.type != "cuda":
+            raise RuntimeError("explainn_amd.PWM runs only on a HIP device; call .cuda()")
+        if x.dim() != 3 or x.shape[1] != 4 or x.shape[2] != o["sequence_length"] or x.device != w.device:
+            raise RuntimeError("expected input of shape (B, 4, %d) on %s" % (o["sequence_length"], w.device))
+        x = x.detach().to(torch.float32).contiguous()
+        scores = torch.empty(x.shape[0], o["groups"], device=w.device, dtype=torch.float32)
+        lib = _lib.load()
+        with torch.cuda.device(w.device):
+            _lib.check(lib.explainn_pwm_scan(
+                x.data_ptr(), x.shape[0], o["sequence_length"], w.detach().contiguous().data_ptr(),
+                o["groups"], o["kernel_size"],
+                _lib.PWM_MAX if o["scoring"] == "max" else _lib.PWM_SUM, scores.data_ptr(),
+                C.c_void_p(torch.cuda.current_stream(w.device).cuda_stream)))
+        # the reference adds conv1d.bias (zeros by construction) to every window score
+        windows = 1 if o["scoring"] == "max" else 2 * (o["sequence_length"] - o["kernel_size"] + 1)
+        return scores.add_(self.conv1d.bias.detach() * windows)
 
 
 # ----------------------------------------------------------------------------------------------

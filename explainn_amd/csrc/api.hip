@@ -233,6 +233,13 @@ extern "C" int explainn_unit_activations(explainn_ctx* c, const float* x, int B,
     return EXPLAINN_OK;
 }
 
+extern "C" int explainn_stage_codes(explainn_ctx* c, const uint8_t* codes, int B,
+                                    int reverse_complement, void* stream) {
+    TRY(check_batch(c, B));
+    if (!codes) { explainn_set_error("codes is null"); return EXPLAINN_E_ARG; }
+    return launch_pack_codes(c, codes, B, reverse_complement ? 1 : 0, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int explainn_filter_act_max(explainn_ctx* c, const float* x, int B,
                                        const explainn_params* p, const uint8_t* select,
                                        float* unit_max, void* stream) {

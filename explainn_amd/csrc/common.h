@@ -79,6 +79,7 @@ struct explainn_ctx {
     float* S12p;          // [U][Bs/32][2]    per 32-sequence tile: sum dy, sum dy*chat
     float* Dspp;          // [U][Bs/64][4k]
     float* dlogits;       // [maxB][T]         (train_step only)
+    int staged_B;         // batch size of the codes explainn_stage_codes() staged, 0 = none
     int* flags;           // [1]
     int* site_cnt;        // [U4][Bs]  sites per (unit, sequence) of the current batch (filter->PWM export)
     int* site_off;        // [U4][Bs]  their exclusive scan in sequence order, plus the running total
@@ -103,6 +104,7 @@ int launch_prep1(explainn_ctx* c, const explainn_params* p, int B, bool train, h
 int launch_moments(explainn_ctx* c, int B, hipStream_t s);
 int launch_prep1_tables(explainn_ctx* c, const explainn_params* p, hipStream_t s);
 int launch_conv_pool(explainn_ctx* c, const explainn_params* p, int B, hipStream_t s);
+int launch_pack_codes(explainn_ctx* c, const uint8_t* codes, int B, int rc, hipStream_t s);
 int launch_conv_act(explainn_ctx* c, int B, float* acts, hipStream_t s);
 int launch_filter_act_max(explainn_ctx* c, int B, const uint8_t* select, float* umax, hipStream_t s);
 int launch_filter_sites(explainn_ctx* c, int B, const uint8_t* select, const float* thr, int cap,

@@ -10,7 +10,14 @@
 // This is the only stage that touches the HBM-resident input: 16*L bytes per sequence.
 #include "common.h"
 
+// CODES = false: x is the fp32 one-hot (B,4,L).  CODES = true: `codes_in` is a
+// (B,L) byte matrix of base codes 0..3 = A,C,G,T, 4 = N -- 16x less input traffic, no fp32 one-hot
+// in HBM at all -- optionally reverse-complemented on the fly (code' [p] = 3 - code[L-1-p], N stays
+// N: sequence/__init__.py:59-61 flips both axes of the one-hot).
+template <bool CODES>
 __global__ __launch_bounds__(256) void pack_onehot_kernel(const float* __restrict__ x,
+                                                          const uint8_t* __restrict__ codes_in,
+                                                          int rc,
                                                           uint8_t* __restrict__ codesT,
                                                           uint32_t* __restrict__ pk2,
                                                           uint32_t* __restrict__ nmask, int B,
@@ -22,6 +29,26 @@ __global__ __launch_bounds__(256) void pack_onehot_kernel(const float* __restric
     int bad = 0;
     const int p = p0 + lane;
     const int pc = min(p, L - 1);
+    if (CODES) {
+        const int ps = rc ? L - 1 - pc : pc;            // source position of output position p
+        for (int i0 = q; i0 < 64; i0 += 16) {
+            int v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = codes_in[(size_t)min(b0 + i0 + 4 * r, B - 1) * L + ps];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) KEEP(v[r]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + 4 * r, b = b0 + i;
+                uint8_t code = (p < L) ? 4 : 0;
+                if (b < B && p < L) {
+                    if (v[r] < 4) code = rc ? 3 - v[r] : v[r];
+                    else if (v[r] != 4) bad = 1;        // not a base code: treated as N, flagged
+                }
+                tile[i][lane] = code;
+            }
+        }
+    } else {
     // four sequences (16 loads) per pass, all issued before any is used (see KEEP in common.h)
     for (int i0 = q; i0 < 64; i0 += 16) {
         float v[4][4];
@@ -49,6 +76,7 @@ __global__ __launch_bounds__(256) void pack_onehot_kernel(const float* __restric
             }
             tile[i][lane] = code;
         }
+    }
     }
     __syncthreads();
     for (int pp = q; pp < 64; pp += 4) {
@@ -144,11 +172,31 @@ int launch_moments(explainn_ctx* c, int B, hipStream_t s);
 
 int launch_pack(explainn_ctx* c, const float* x, int B, bool counts, hipStream_t s) {
     const int gb = (B + 63) / 64;
-    // position tiles cover the padded tail too, so the packed words past L are written (as zeros)
-    hipLaunchKernelGGL(pack_onehot_kernel, dim3(gb, (c->NW * 32 + 63) / 64), dim3(256), 0, s, x,
-                       c->codesT, c->pk2, c->nmask, B, c->L, c->Bs, c->PW, c->NW, c->flags);
-    LAUNCH_CHECK();
+    if (x == nullptr) {
+        // x == NULL: run on the base codes explainn_stage_codes() left in the context
+        if (c->staged_B != B) {
+            explainn_set_error("x is NULL but %s (batch %d)", c->staged_B ? "the staged codes hold "
+                               "another batch size" : "no codes are staged", B);
+            return EXPLAINN_E_STATE;
+        }
+    } else {
+        c->staged_B = 0;
+        // position tiles cover the padded tail too, so the packed words past L are written (as zeros)
+        hipLaunchKernelGGL(pack_onehot_kernel<false>, dim3(gb, (c->NW * 32 + 63) / 64), dim3(256), 0,
+                           s, x, (const uint8_t*)nullptr, 0, c->codesT, c->pk2, c->nmask, B, c->L,
+                           c->Bs, c->PW, c->NW, c->flags);
+        LAUNCH_CHECK();
+    }
     if (counts) return launch_moments(c, B, s);
+    return EXPLAINN_OK;
+}
+
+int launch_pack_codes(explainn_ctx* c, const uint8_t* codes, int B, int rc, hipStream_t s) {
+    hipLaunchKernelGGL(pack_onehot_kernel<true>, dim3((B + 63) / 64, (c->NW * 32 + 63) / 64),
+                       dim3(256), 0, s, (const float*)nullptr, codes, rc, c->codesT, c->pk2, c->nmask,
+                       B, c->L, c->Bs, c->PW, c->NW, c->flags);
+    LAUNCH_CHECK();
+    c->staged_B = B;
     return EXPLAINN_OK;
 }
 

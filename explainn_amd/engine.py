@@ -45,15 +45,18 @@ class StepEngine:
             p.grad = v
 
     def step(self, x, y, seed=None, freeze_top_n_filters=0):
-        """x (B,4,L) fp32 one-hot, y (B,T) fp32, both resident on the device.  Enqueues one
-        train-mode forward + loss + backward; returns (logits view, loss tensor) without syncing."""
+        """x (B,4,L) fp32 one-hot -- or base codes (uint8 (B,L) / architectures.BaseCodes) -- and
+        y (B,T) fp32, both resident on the device.  Enqueues one train-mode forward + loss +
+        backward; returns (logits view, loss tensor) without syncing."""
         B = x.shape[0]
         if seed is None:
             self.step_no += 1
             seed = self.step_no * 0x9E3779B97F4A7C15 & 0xFFFFFFFFFFFFFFFF
         m = self.model
+        if not (torch.is_tensor(x) and x.dtype == torch.float32):
+            x = m._prep_input(x, self.dev)
         _lib.check(self.ctx.lib.explainn_train_step(
-            self.ctx.handle, x.data_ptr(), y.data_ptr(), B, C.byref(self.ps), C.byref(self.gs),
+            self.ctx.handle, m._x_ptr(self.ctx, x, self.dev), y.data_ptr(), B, C.byref(self.ps), C.byref(self.gs),
             self.loss_kind, float(m.dropout_p), C.c_uint64(seed), int(freeze_top_n_filters),
             self.logits.data_ptr(), self.loss.data_ptr(),
             C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))

@@ -28,9 +28,25 @@ def _load_model(model_file):
 
 
 def predict(model, Xs, batch_size=100, apply_sigmoid=False):
-    """Xs: (N,4,L) one-hot (numpy or tensor, host).  Returns (N, T, 4) float64."""
-    Xs = torch.as_tensor(np.asarray(Xs), dtype=torch.float32)
+    """Xs: (N,4,L) one-hot (numpy or tensor, host) -- or (N,L) uint8 base codes
+    (sequence.encode_codes_many), in which case the reverse strand is read on the fly from the same
+    bytes.  Returns (N, T, 4) float64."""
     device = model.final.weight.device
+    Xs_np = np.asarray(Xs)
+    if Xs_np.dtype == np.uint8 and Xs_np.ndim == 2:
+        from .architectures import BaseCodes
+        codes = torch.from_numpy(np.ascontiguousarray(Xs_np))
+        out = np.empty((len(codes), model._options["n_features"], 4))
+        with torch.no_grad():
+            for i in range(0, len(codes), batch_size):
+                cb = codes[i:i + batch_size].to(device)
+                fwd = model(BaseCodes(cb)).cpu().numpy()[:, :, None]
+                rev = model(BaseCodes(cb, reverse_complement=True)).cpu().numpy()[:, :, None]
+                fr = np.concatenate((fwd, rev), axis=2)
+                out[i:i + fwd.shape[0]] = np.concatenate(
+                    (fwd, rev, fr.mean(axis=2, keepdims=True), fr.max(axis=2, keepdims=True)), axis=2)
+        return torch.sigmoid(torch.Tensor(out)).numpy() if apply_sigmoid else out
+    Xs = torch.as_tensor(Xs_np, dtype=torch.float32)
     out = np.empty((len(Xs), model._options["n_features"], 4))
     with torch.no_grad():
         for i in range(0, len(Xs), batch_size):

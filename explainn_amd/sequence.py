@@ -17,6 +17,32 @@ def encode_codes(seq):
     return _LUT[np.frombuffer(seq.encode("ascii", "replace"), dtype=np.uint8)]
 
 
+def encode_codes_many(seqs):
+    """(N, L) uint8 base codes of equal-length sequences: the input format of
+    architectures.BaseCodes (L bytes per sequence instead of the 32*L of a float64 one-hot)."""
+    out = np.empty((len(seqs), len(seqs[0]) if len(seqs) else 0), dtype=np.uint8)
+    for i, s in enumerate(seqs):
+        c = encode_codes(s)
+        if len(c) != out.shape[1]:
+            raise ValueError("sequence %d has length %d, expected %d" % (i, len(c), out.shape[1]))
+        out[i] = c
+    return out
+
+
+def rc_codes(codes):
+    """Reverse complement on base codes (what rc_one_hot_encoding does to the one-hot): reverse,
+    A<->T, C<->G, N stays N."""
+    codes = np.asarray(codes)
+    r = codes[..., ::-1]
+    return np.where(r < 4, 3 - r, r).astype(np.uint8)
+
+
+def codes_to_one_hot(codes, dtype=np.float32):
+    """(N, L) codes -> (N, 4, L) one-hot (N columns all zero)."""
+    codes = np.asarray(codes)
+    return (codes[:, None, :] == np.arange(4, dtype=np.uint8)[None, :, None]).astype(dtype)
+
+
 def one_hot_encode(seq):
     """sequence/__init__.py:8-28 -> float64 (4, L)."""
     codes = encode_codes(seq)

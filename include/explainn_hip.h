@@ -150,6 +150,25 @@ int explainn_filter_sites(explainn_ctx* ctx, const float* x, int B, const explai
                           const uint8_t* select, const float* thresholds, int site_cap,
                           int32_t* site_total, int32_t* pfm, uint8_t* hit, void* stream);
 
+/* Base-code input: instead of the fp32 one-hot (16*L bytes per sequence) hand the
+ * sequences over as a (B,L) byte matrix of base codes -- 0,1,2,3 = A,C,G,T, 4 = N, the integers
+ * sequence.one_hot_encode (sequence/__init__.py:8-28) turns into one-hot columns -- and let the
+ * kernel reverse-complement them on the fly when reverse_complement != 0 (the augmentation of
+ * train.py:275-278 / predict.py:78-79 without a second copy of the data).  The codes are packed
+ * into the context; every entry point above that takes `x` then accepts x == NULL, meaning "the
+ * staged batch" (B must match, else EXPLAINN_E_STATE; passing a real x discards the staged batch).
+ * Other byte values are treated as N and raise bit 0 of explainn_input_flags. */
+int explainn_stage_codes(explainn_ctx* ctx, const uint8_t* codes, int B, int reverse_complement,
+                         void* stream);
+
+/* PWM scan: the reference's `PWM` module forward (architectures/__init__.py:157-168).
+ * x: fp32 (B,4,L) rows A,C,G,T; pwms: fp32 (G,4,k); scores: fp32 (B,G) = max (EXPLAINN_PWM_MAX) or
+ * sum (EXPLAINN_PWM_SUM) of the window scores over both strands.  No context needed. */
+#define EXPLAINN_PWM_SUM 0
+#define EXPLAINN_PWM_MAX 1
+int explainn_pwm_scan(const float* x, int B, int L, const float* pwms, int G, int k, int scoring,
+                      float* scores, void* stream);
+
 /* Input validation result of every pack since the last call: bit 0 set = some column of x was
  * neither one-hot nor all-zero (such columns were treated as N).  Synchronises `stream`,
  * writes the flags to *flags_host and clears them. */

@@ -205,6 +205,23 @@ def predict_fwd_rev(sd, x, dtype=np.float32):
     return out.astype(np.float64)
 
 
+def pwm_scan(pwms, x, scoring="sum", dtype=np.float64):
+    """The reference `PWM.forward` (architectures/__init__.py:157-168): valid cross-correlation of
+    each (4,k) matrix with x and with its reverse complement (both axes flipped), then the max or
+    the sum over all 2*(L-k+1) window scores -> (B,G).  Bias is zero by construction (:151)."""
+    pwms = np.asarray(pwms, dtype=dtype)
+    x = np.asarray(x, dtype=dtype)
+    G, _, k = pwms.shape
+    Lo = x.shape[2] - k + 1
+
+    def scan(xx):
+        win = np.stack([xx[:, :, j:j + Lo] for j in range(k)], axis=3)       # (B,4,Lo,k)
+        return np.einsum("balk,gak->bgl", win, pwms)
+
+    o = np.concatenate((scan(x), scan(x[:, ::-1, ::-1])), axis=2)
+    return o.max(axis=2) if scoring == "max" else o.sum(axis=2)
+
+
 # ----------------------------------------------------------------------------
 # losses (architectures/__init__.py:446-456), mean reduction
 # ----------------------------------------------------------------------------

@@ -119,3 +119,35 @@ def test_export_needs_eval_mode_and_checks_shapes():
     with pytest.raises(RuntimeError):
         net.filter_sites(x, torch.zeros(3).cuda(), torch.zeros(4, dtype=torch.int32).cuda(),
                          torch.zeros(4, 5, 4, dtype=torch.int32).cuda())
+
+
+@pytest.mark.parametrize("scoring", ["max", "sum"])
+def test_pwm_module_golden(scoring):
+    """explainn_amd.PWM against the reference PWM module's scores (tolerance 1e-4 relative to the
+    largest score: fp32 sums in a different order)."""
+    import os
+    from conftest import GOLDEN
+    from explainn_amd import PWM
+    z = np.load(os.path.join(GOLDEN, "pwm_scan.npz"), allow_pickle=False)
+    mod = PWM(z["pwms"], z["x"].shape[2], scoring)
+    assert sorted(mod.state_dict().keys()) == [str(s) for s in z["state_keys"]]
+    assert not any(p.requires_grad for p in mod.parameters())
+    with pytest.raises(RuntimeError):
+        mod(torch.from_numpy(z["x"]))                        # no CPU fallback
+    got = mod.cuda()(torch.from_numpy(z["x"]).cuda()).cpu().numpy()
+    assert got.shape == z[scoring].shape
+    assert np.abs(got - z[scoring]).max() <= 1e-4 * max(1.0, np.abs(z[scoring]).max())
+
+
+def test_pwm_scan_wide_bank_vs_oracle():
+    """A 300-matrix bank over 200 bp (ragged last quad, k = 19) against the fp64 oracle."""
+    from explainn_amd import PWM
+    from oracle import explainn_oracle as eo
+    g = np.random.default_rng(3)
+    pwms = g.standard_normal((301, 4, 19)).astype(np.float32)
+    codes = g.integers(0, 5, size=(33, 200)).astype(np.uint8)
+    x = onehot(codes)
+    for scoring in ("max", "sum"):
+        got = PWM(pwms, 200, scoring).cuda()(torch.from_numpy(x).cuda()).cpu().numpy()
+        ref = eo.pwm_scan(pwms, x, scoring)
+        assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())

@@ -273,3 +273,61 @@ def test_step_engine_vs_oracle(T, kind):
             assert np.abs(_np(v)).max() < 1e-6, key
         else:
             _close(_np(v).reshape(ref_grads[key].shape), ref_grads[key], tol=2e-4, what="grad " + key)
+
+
+# ---- base-code input: same numbers as the fp32 one-hot, bit for bit ------------
+def test_base_codes_equal_onehot_path():
+    from explainn_amd.architectures import BaseCodes
+    from explainn_amd.engine import StepEngine
+    from explainn_amd import predict as pr
+    from explainn_amd import sequence as sq
+    g = Golden("mid_u8_k19_L200")
+    codes = g.codes[:g.B]
+    x = torch.from_numpy(g.onehot()).cuda()
+    c = torch.from_numpy(codes).cuda()
+    m = _model(g.sd(), g.U, g.k, g.L, g.T).eval()
+    with torch.no_grad():
+        assert torch.equal(m(c), m(x))
+        assert torch.equal(m(BaseCodes(c, True)), m(torch.flip(x, dims=(1, 2))))
+        assert torch.equal(m.linears(c), m.linears(x.repeat(1, g.U, 1)))
+        assert torch.equal(m.linears[:3](BaseCodes(c)), m.linears[:3](x))
+    assert np.array_equal(sq.rc_codes(codes), sq.encode_codes_many(
+        [sq.rc(s) for s in sq.one_hot_decode_many(g.onehot())]))
+    assert np.array_equal(sq.codes_to_one_hot(codes), g.onehot())
+    assert np.array_equal(pr.predict(m, codes, batch_size=5), pr.predict(m, g.onehot(), batch_size=5))
+    # train step: identical logits, loss and flat gradient from either input form
+    y = torch.from_numpy(g.targets().astype(np.float32)).cuda()
+    res = []
+    for inp in (x, c):
+        mm = _model(g.sd(), g.U, g.k, g.L, g.T).train()
+        eng = StepEngine(mm, g.B, loss=g.loss_kind)
+        logits, loss = eng.step(inp, y, seed=7)
+        res.append((logits.clone(), loss.clone(), eng.flat_grad.clone()))
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    # autograd path
+    mm = _model(g.sd(), g.U, g.k, g.L, g.T).train()
+    mm.dropout_p = 0.0
+    out = mm(BaseCodes(c))
+    out.sum().backward()
+    assert mm.final.weight.grad is not None and torch.isfinite(mm.final.weight.grad).all()
+
+
+def test_base_codes_errors():
+    from explainn_amd import _lib
+    g = Golden("tiny_u3_k5_N")
+    m = _model(g.sd(), g.U, g.k, g.L, g.T).eval()
+    bad = torch.from_numpy(g.codes[:4].copy()).cuda()
+    bad[0, 0] = 9                                              # not a base code
+    with pytest.raises(ValueError):
+        m(bad)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(4, g.L + 1, dtype=torch.uint8).cuda())    # wrong length
+    # x == NULL without staged codes is a state error, not a crash
+    ctx = m._context(4, m._device())
+    ps, keep = m._params_struct(m._device())
+    out = torch.empty(4, g.T).cuda()
+    import ctypes
+    m(torch.from_numpy(g.onehot()[:4]).cuda())                  # a real x discards staged codes
+    rc = ctx.lib.explainn_forward_eval(ctx.handle, None, 4, ctypes.byref(ps), out.data_ptr(), None)
+    assert rc == _lib.E_STATE

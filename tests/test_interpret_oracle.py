@@ -79,3 +79,11 @@ def test_jaspar_layout():
     txt = it.format_jaspar(np.array([[1, 2, 3, 4], [10, 0, 0, 0]]), "filter0", "demo")
     assert txt.splitlines() == [">filter0 demo", "A [  1.00  10.00]", "C [  2.00   0.00]",
                                 "G [  3.00   0.00]", "T [  4.00   0.00]"]
+
+
+@pytest.mark.parametrize("scoring", ["max", "sum"])
+def test_pwm_scan_oracle_matches_reference(scoring):
+    from oracle import explainn_oracle as eo
+    z = np.load(os.path.join(GOLDEN, "pwm_scan.npz"), allow_pickle=False)
+    got = eo.pwm_scan(z["pwms"], z["x"], scoring)
+    assert np.abs(got - z[scoring]).max() <= 1e-4 * max(1.0, np.abs(z[scoring]).max())

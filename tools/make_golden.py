@@ -24,7 +24,7 @@ sys.path.insert(0, "/root/reference/explainn")
 import numpy as np
 import torch
 
-from architectures import ExplaiNN, get_loss, get_optimizer   # noqa: E402  (reference)
+from architectures import ExplaiNN, PWM, get_loss, get_optimizer   # noqa: E402  (reference)
 import sequence as ref_sequence                                 # noqa: E402  (reference)
 
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
@@ -246,6 +246,24 @@ def make_encoding_case():
     print("encoding")
 
 
+def make_pwm_case():
+    """The reference `PWM` module (architectures/__init__.py:116-170) on random log-odds matrices:
+    max and sum scoring, with N columns and one soft (non-one-hot) sequence."""
+    g = np.random.default_rng(40)
+    G, k, L, B = 6, 11, 50, 9
+    pwms = g.standard_normal((G, 4, k)).astype(np.float32)
+    codes = make_codes(B, L, 41, 0.05)
+    x = codes_to_onehot(codes)
+    x[-1] = g.random((4, L)).astype(np.float32)          # the module is a plain convolution
+    out = {"pwms": pwms, "x": x}
+    for scoring in ("max", "sum"):
+        with torch.no_grad():
+            out[scoring] = PWM(pwms, L, scoring)(torch.from_numpy(x)).numpy()
+    out["state_keys"] = np.array(sorted(PWM(pwms, L).state_dict().keys()))
+    np.savez_compressed(os.path.join(OUT, "pwm_scan.npz"), **out)
+    print("pwm_scan", out["max"].shape)
+
+
 def make_pfm_case(name, U, k, L, T, N, seed, rev_complement, loss_kind="binary", n_frac=0.0, cap=None):
     """Filter -> PWM fixture.  The float16 activations / unit outputs / predictions
     come from the imported reference model exactly as test.py:128-166 extracts them (x.repeat ->
@@ -321,6 +339,9 @@ if __name__ == "__main__":
     make_encoding_case()
     if len(sys.argv) > 1 and sys.argv[1] == "trainer":
         make_trainer_case()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "pwm":
+        make_pwm_case()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "pfm":
         #             name              U   k   L  T   N seed  rc
