@@ -146,14 +146,29 @@ def main():
     fence()
     wall = time.perf_counter() - t0
     gpu_ms = ev0.elapsed_time(ev1)       # HIP events on the launch stream (torch current stream)
+    # secondary figure ("report with and without the optimiser step"): the same step
+    # followed by the fused Adam update, timed the same way; not part of `value`
+    from explainn_amd import get_optimizer
+    opt = get_optimizer(model.parameters(), lr=0.003)
+    eng.attach_grads()
+    for i in range(3):
+        one_step(i)
+        opt.step()
+    fence()
+    t1 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + args.steps + i)
+        opt.step()
+    fence()
+    wall_opt = time.perf_counter() - t1
     flags = model.input_flags()
     assert flags == 0, "synthetic input flagged as not one-hot"
     assert torch.isfinite(eng.loss).all() and torch.isfinite(eng.flat_grad).all()
 
-    t = torch.tensor([wall], device=dev, dtype=torch.float64)
+    t = torch.tensor([wall, wall_opt], device=dev, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall = float(t.item())
+    wall, wall_opt = float(t[0].item()), float(t[1].item())
     if rank == 0:
         seqs = B_PER_GPU * world * args.steps
         step_gpu_s = gpu_ms / 1e3 / args.steps
@@ -180,6 +195,9 @@ def main():
                          "algorithmic_bytes_per_step": alg,
                          "gpu_ms_per_step_hip_events": round(step_gpu_s * 1e3, 4)},
         }
+        out["with_optimizer"] = {"ms_per_step": round(wall_opt / args.steps * 1e3, 4),
+                                 "value": round(seqs / wall_opt, 1), "unit": "sequences/s",
+                                 "optimizer": "Adam(lr=0.003), one fused launch (csrc/adam.hip)"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         else:

@@ -45,7 +45,7 @@ EXPORTS = (
     "explainn_forward_eval", "explainn_forward_train", "explainn_backward", "explainn_loss_grad",
     "explainn_train_step", "explainn_unit_outputs", "explainn_unit_activations",
     "explainn_input_flags", "explainn_filter_act_max", "explainn_filter_sites",
-    "explainn_pwm_scan", "explainn_stage_codes",
+    "explainn_pwm_scan", "explainn_stage_codes", "explainn_adam_step",
 )
 
 
@@ -105,6 +105,10 @@ def load():
     lib.explainn_filter_sites.restype = C.c_int
     lib.explainn_stage_codes.argtypes = [ctx, _fp, C.c_int, C.c_int, _fp]
     lib.explainn_stage_codes.restype = C.c_int
+    lib.explainn_adam_step.argtypes = [C.c_int, C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp),
+                                       C.POINTER(_fp), C.POINTER(C.c_int64), C.c_int64, C.c_double,
+                                       C.c_double, C.c_double, C.c_double, _fp]
+    lib.explainn_adam_step.restype = C.c_int
     lib.explainn_pwm_scan.argtypes = [_fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp]
     lib.explainn_pwm_scan.restype = C.c_int
     lib.explainn_input_flags.argtypes = [ctx, C.POINTER(C.c_int), _fp]

@@ -560,5 +560,7 @@ def get_metrics(input_data="binary"):
 
 
 def get_optimizer(params, lr=1e-03):
-    """architectures/__init__.py:463-464."""
-    return torch.optim.Adam(params, lr=lr)
+    """architectures/__init__.py:463-464: Adam with torch's defaults.  The object returned is a
+    torch.optim.Adam whose step() runs as one HIP launch (optim.FusedAdam)."""
+    from .optim import FusedAdam
+    return FusedAdam(params, lr=lr)

@@ -85,7 +85,9 @@ class Trainer(object):
         if self.use_cuda:
             for state in self.optimizer.state.values():
                 for k, v in state.items():
-                    if isinstance(v, torch.Tensor):
+                    # the step counter stays on the host (torch's Adam requires it there unless
+                    # capturable; the reference's blanket .cuda() predates that check)
+                    if isinstance(v, torch.Tensor) and k != "step":
                         state[k] = v.cuda()
         self.logger.info("Resuming from checkpoint: step %s, min loss %s" % (
             self._start_step, self._min_loss))

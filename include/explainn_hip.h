@@ -169,6 +169,16 @@ int explainn_stage_codes(explainn_ctx* ctx, const uint8_t* codes, int B, int rev
 int explainn_pwm_scan(const float* x, int B, int L, const float* pwms, int G, int k, int scoring,
                       float* scores, void* stream);
 
+/* One Adam step over n_tensors parameter tensors in a single launch -- torch.optim.Adam(params, lr)
+ * with its defaults, the optimiser the reference builds (architectures/__init__.py:463-464) and
+ * steps at selene/__init__.py:291.  params/grads/exp_avg/exp_avg_sq: HOST arrays of n_tensors
+ * device pointers (fp32, contiguous), sizes: HOST array of element counts; step: 1 for the first
+ * update; the hyper-parameters are doubles because torch derives 1-beta and the bias corrections
+ * from Python floats (1.f - 0.999f is off by 5e-5).  No context needed. */
+int explainn_adam_step(int n_tensors, float* const* params, const float* const* grads,
+                       float* const* exp_avg, float* const* exp_avg_sq, const int64_t* sizes,
+                       int64_t step, double lr, double beta1, double beta2, double eps, void* stream);
+
 /* Input validation result of every pack since the last call: bit 0 set = some column of x was
  * neither one-hot nor all-zero (such columns were treated as N).  Synchronises `stream`,
  * writes the flags to *flags_host and clears them. */

@@ -331,3 +331,40 @@ def test_base_codes_errors():
     m(torch.from_numpy(g.onehot()[:4]).cuda())                  # a real x discards staged codes
     rc = ctx.lib.explainn_forward_eval(ctx.handle, None, 4, ctypes.byref(ps), out.data_ptr(), None)
     assert rc == _lib.E_STATE
+
+
+# ---- fused Adam (architectures/__init__.py:463-464 -> torch.optim.Adam defaults) ----------------
+def test_fused_adam_matches_torch_adam():
+    from explainn_amd import get_optimizer
+    from explainn_amd.optim import FusedAdam
+    torch.manual_seed(3)
+    shapes = [(300, 4, 19), (300,), (30000, 26, 1), (1, 300), (1,), (5000,), (7, 3)]
+    pa = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa, ob = get_optimizer(pa, lr=0.003), torch.optim.Adam(pb, lr=0.003)
+    assert isinstance(oa, FusedAdam) and isinstance(oa, torch.optim.Adam)
+    for it in range(25):
+        for a, b in zip(pa, pb):
+            g = torch.randn_like(a) * (10.0 ** ((it % 5) - 3))
+            a.grad, b.grad = g.clone(), g.clone()
+        oa.step(); ob.step()
+    for a, b in zip(pa, pb):
+        assert torch.allclose(a, b, rtol=2e-6, atol=2e-7), (a - b).abs().max()
+    sa, sb = oa.state_dict(), ob.state_dict()
+    assert sa["param_groups"][0].keys() == sb["param_groups"][0].keys()
+    for i in sb["state"]:
+        assert sa["state"][i].keys() == sb["state"][i].keys()
+        assert float(sa["state"][i]["step"]) == float(sb["state"][i]["step"]) == 25.0
+        for k in ("exp_avg", "exp_avg_sq"):
+            ref = sb["state"][i][k]
+            assert torch.allclose(sa["state"][i][k], ref, rtol=2e-6, atol=1e-6 * float(ref.abs().max()))
+    # a state dict written by torch's Adam resumes in the fused one (checkpoint compatibility)
+    oc = get_optimizer(pa, lr=0.003)
+    oc.load_state_dict(sb)
+    for a in pa:
+        a.grad = torch.ones_like(a)
+    oc.step()
+    assert float(oc.state_dict()["state"][0]["step"]) == 26.0
+    # options the kernel does not implement fall through to torch's own step
+    od = FusedAdam(pa, lr=0.003, weight_decay=0.1)
+    od.step()
