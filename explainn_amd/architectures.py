@@ -194,6 +194,9 @@ class ExplaiNN(_Model):
             "n_features": n_features,
             "weights_file": weights_file,
         }
+        if cnn_units < 1 or n_features < 1 or kernel_size < 1:
+            # torch's Conv1d/Linear constructors reject these in the reference
+            raise ValueError("cnn_units, kernel_size and n_features must be positive")
         n = int(math.floor((sequence_length - kernel_size + 1) / float(POOL)))
         if n < 1:
             raise ValueError("sequence_length too short for kernel_size and MaxPool1d(7, 7)")

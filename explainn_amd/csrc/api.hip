@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <cstdlib>
+
 #include "common.h"
 
 static thread_local char g_err[512] = "";
@@ -156,6 +158,9 @@ extern "C" int explainn_create(explainn_ctx** out, int cnn_units, int kernel_siz
         if (a > 16) a = 16;
         if (a < 1) a = 1;
         c->ACH = a;
+        // tuning overrides (experiments only; defaults above are what is tested and benchmarked)
+        if (const char* e = getenv("EXPLAINN_ACH")) { const int v = atoi(e); if (v >= 1 && v <= 16) c->ACH = v; }
+        if (const char* e = getenv("EXPLAINN_QCH")) { const int v = atoi(e); if (v >= 1 && v <= cap && v <= 8) c->QCH = v; }
     }
     Carver dry;
     carve(c, dry);

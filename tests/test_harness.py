@@ -121,3 +121,34 @@ def test_train_entry_point_and_predict_roundtrip(tmp_path):
     assert np.abs(preds[:, :, 0] - fwd).max() < 1e-6 and np.abs(preds[:, :, 1] - rev).max() < 1e-6
     assert np.allclose(preds[:, :, 2], (fwd + rev) / 2, atol=1e-6)
     assert np.allclose(preds[:, :, 3], np.maximum(fwd, rev), atol=1e-6)
+
+
+def test_constructor_contract_on_cpu():
+    """The façade keeps the reference's constructor surface (architectures/__init__.py:44-107):
+    _options keys, state_dict keys/shapes, and the same rejections torch's layers raise there."""
+    import torch
+    from explainn_amd import ExplaiNN
+    m = ExplaiNN(3, 5, 40, 2)
+    assert list(m._options) == ["cnn_units", "kernel_size", "sequence_length", "n_features", "weights_file"]
+    sd = m.state_dict()
+    n = (40 - 5 + 1) // 7
+    assert sd["linears.0.weight"].shape == (3, 4, 5) and sd["linears.6.weight"].shape == (300, n, 1)
+    assert sd["linears.10.weight"].shape == (3, 100, 1) and sd["final.weight"].shape == (2, 3)
+    assert m.__class__.__name__ == "ExplaiNN"
+    for bad in ((0, 5, 40, 1), (3, 5, 40, 0), (3, 0, 40, 1), (3, 19, 24, 1)):
+        with pytest.raises(ValueError):
+            ExplaiNN(*bad)
+    with pytest.raises(RuntimeError):          # no CPU fallback: the model must be on a HIP device
+        m(torch.zeros(2, 4, 40))
+
+
+def test_codes_helpers_roundtrip():
+    from explainn_amd import sequence as sq
+    seqs = ["ACGTNACGT", "ttgacnnAC"]
+    codes = sq.encode_codes_many(seqs)
+    assert codes.dtype == np.uint8 and codes.shape == (2, 9)
+    assert np.array_equal(sq.codes_to_one_hot(codes, float), sq.one_hot_encode_many(seqs))
+    assert np.array_equal(sq.codes_to_one_hot(sq.rc_codes(codes), float),
+                          sq.rc_one_hot_encoding_many(sq.one_hot_encode_many(seqs)))
+    with pytest.raises(ValueError):
+        sq.encode_codes_many(["ACG", "AC"])
