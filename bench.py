@@ -105,10 +105,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # EXPLAINN_BENCH_FORCE_SYNC=1: rehearse the N > 1 code path (process group, overlapped RCCL
+    # all-reduce, barriers) in a one-rank group on a single GPU; the collectives are identities
+    force_sync = world == 1 and os.environ.get("EXPLAINN_BENCH_FORCE_SYNC") == "1"
+    if world > 1 or force_sync:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from explainn_amd import ExplaiNN
     from explainn_amd.engine import StepEngine
@@ -120,14 +124,15 @@ def main():
     if world > 1:
         broadcast_parameters(model)
     eng = StepEngine(model, B_PER_GPU, loss="binary")
-    sync = GradAllReduce(eng.flat_grad) if world > 1 else None
+    # the all-reduce of the FC/head gradients (97 % of the buffer) starts as soon as they are final
+    # and runs under the filter-bank backward; the small remainder follows the step
+    sync = (GradAllReduce(eng.flat_grad, split=eng.conv_grad_elements, force=force_sync)
+            if dist is not None else None)
     P = eng.flat_grad.numel()
     x, y = synthetic_batch(B_PER_GPU, 1000 + rank, dev)
 
     def one_step(i):
-        eng.step(x, y, seed=(rank << 40) + i + 1)
-        if sync is not None:
-            sync()
+        eng.step(x, y, seed=(rank << 40) + i + 1, grad_sync=sync)
 
     def fence():
         if dist is not None:
@@ -182,7 +187,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C2: 300-unit ExplaiNN, k=19, 200 bp one-hot, 1 binary task, "
                                    "batch 1024 per GPU, train fwd + BCE + bwd (dropout 0.3)"
-                                   + (", RCCL all-reduce of the flat gradient" if world > 1 else ""),
+                                   + (", RCCL all-reduce of the flat gradient" if dist is not None else ""),
                        "cnn_units": U, "kernel_size": K, "sequence_length": L, "n_features": T,
                        "batch_per_gpu": B_PER_GPU, "global_batch": B_PER_GPU * world,
                        "parameters": P, "parallelism": "dp%d" % world},

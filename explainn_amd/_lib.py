@@ -46,6 +46,7 @@ EXPORTS = (
     "explainn_train_step", "explainn_unit_outputs", "explainn_unit_activations",
     "explainn_input_flags", "explainn_filter_act_max", "explainn_filter_sites",
     "explainn_pwm_scan", "explainn_stage_codes", "explainn_adam_step",
+    "explainn_train_step_fc", "explainn_train_step_conv",
 )
 
 
@@ -95,6 +96,11 @@ def load():
     lib.explainn_train_step.argtypes = [ctx, _fp, _fp, C.c_int, pp, gp, C.c_int, C.c_float,
                                         C.c_uint64, C.c_int, _fp, _fp, _fp]
     lib.explainn_train_step.restype = C.c_int
+    lib.explainn_train_step_fc.argtypes = [ctx, _fp, _fp, C.c_int, pp, gp, C.c_int, C.c_float,
+                                           C.c_uint64, _fp, _fp, _fp]
+    lib.explainn_train_step_fc.restype = C.c_int
+    lib.explainn_train_step_conv.argtypes = [ctx, C.c_int, pp, gp, C.c_int, _fp]
+    lib.explainn_train_step_conv.restype = C.c_int
     lib.explainn_unit_outputs.argtypes = [ctx, _fp, C.c_int, pp, _fp, _fp]
     lib.explainn_unit_outputs.restype = C.c_int
     lib.explainn_unit_activations.argtypes = [ctx, _fp, C.c_int, pp, _fp, _fp]

@@ -305,14 +305,28 @@ extern "C" int explainn_forward_train(explainn_ctx* c, const float* x, int B,
 }
 
 namespace {
-int backward_tail(explainn_ctx* c, int B, const explainn_params* p, const explainn_grads* g,
-                  int freeze_top_n_filters, hipStream_t s) {
+// the backward after the head, in the two halves a data-parallel run overlaps its all-reduce with:
+// after backward_fc every gradient from fc1_w to final_b (the tail of explainn_grads) is final;
+// backward_conv then produces conv_w, conv_b, bn1_w, bn1_b
+int backward_fc(explainn_ctx* c, int B, const explainn_params* p, const explainn_grads* g,
+                hipStream_t s) {
     TRY(launch_passA(c, B, s));
     TRY(launch_mid_bwd(c, p, g, B, s));
+    return EXPLAINN_OK;
+}
+
+int backward_conv(explainn_ctx* c, int B, const explainn_params* p, const explainn_grads* g,
+                  int freeze_top_n_filters, hipStream_t s) {
     TRY(launch_passB(c, B, s));
     TRY(launch_conv_bwd(c, B, s));
     TRY(launch_fin_bwd(c, p, g, B, freeze_top_n_filters, s));
     return EXPLAINN_OK;
+}
+
+int backward_tail(explainn_ctx* c, int B, const explainn_params* p, const explainn_grads* g,
+                  int freeze_top_n_filters, hipStream_t s) {
+    TRY(backward_fc(c, B, p, g, s));
+    return backward_conv(c, B, p, g, freeze_top_n_filters, s);
 }
 }  // namespace
 
@@ -342,24 +356,56 @@ extern "C" int explainn_loss_grad(explainn_ctx* c, int loss_kind, const float* l
                        static_cast<hipStream_t>(stream));
 }
 
-extern "C" int explainn_train_step(explainn_ctx* c, const float* x, const float* targets, int B,
-                                   const explainn_params* p, const explainn_grads* g, int loss_kind,
-                                   float dropout_p, uint64_t seed, int freeze_top_n_filters,
-                                   float* logits, float* loss_out, void* stream) {
+namespace {
+int train_step_front(explainn_ctx* c, const float* x, const float* targets, int B,
+                     const explainn_params* p, const explainn_grads* g, int loss_kind,
+                     float dropout_p, uint64_t seed, float* logits, float* loss_out, void* stream) {
     if (loss_kind != EXPLAINN_LOSS_BCE_WITH_LOGITS && loss_kind != EXPLAINN_LOSS_MSE) {
         explainn_set_error("unknown loss kind %d", loss_kind);
         return EXPLAINN_E_ARG;
     }
+    if (c) c->tail_B = 0;
     TRY(explainn_forward_train(c, x, B, p, nullptr, dropout_p, seed, logits, stream));
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (c->T <= 4) {
         // few tasks: the loss gradient is recomputed inside the head backward (one launch less)
         TRY(launch_head_bwd_fused_loss(c, p, g, loss_kind, logits, targets, loss_out, B, s));
-        return backward_tail(c, B, p, g, freeze_top_n_filters, s);
+    } else {
+        TRY(explainn_loss_grad(c, loss_kind, logits, targets, B, loss_out, c->dlogits, stream));
+        TRY(launch_head_bwd(c, p, g, c->dlogits, B, s));
     }
-    TRY(explainn_loss_grad(c, loss_kind, logits, targets, B, loss_out, c->dlogits, stream));
-    TRY(explainn_backward(c, c->dlogits, B, p, g, freeze_top_n_filters, stream));
+    return backward_fc(c, B, p, g, s);
+}
+}  // namespace
+
+extern "C" int explainn_train_step(explainn_ctx* c, const float* x, const float* targets, int B,
+                                   const explainn_params* p, const explainn_grads* g, int loss_kind,
+                                   float dropout_p, uint64_t seed, int freeze_top_n_filters,
+                                   float* logits, float* loss_out, void* stream) {
+    TRY(train_step_front(c, x, targets, B, p, g, loss_kind, dropout_p, seed, logits, loss_out, stream));
+    return backward_conv(c, B, p, g, freeze_top_n_filters, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int explainn_train_step_fc(explainn_ctx* c, const float* x, const float* targets, int B,
+                                      const explainn_params* p, const explainn_grads* g,
+                                      int loss_kind, float dropout_p, uint64_t seed, float* logits,
+                                      float* loss_out, void* stream) {
+    TRY(train_step_front(c, x, targets, B, p, g, loss_kind, dropout_p, seed, logits, loss_out, stream));
+    c->tail_B = B;
     return EXPLAINN_OK;
+}
+
+extern "C" int explainn_train_step_conv(explainn_ctx* c, int B, const explainn_params* p,
+                                        const explainn_grads* g, int freeze_top_n_filters,
+                                        void* stream) {
+    TRY(check_batch(c, B));
+    if (c->tail_B != B) {
+        explainn_set_error("train_step_conv(B=%d) without a matching train_step_fc (pending B=%d)",
+                           B, c->tail_B);
+        return EXPLAINN_E_STATE;
+    }
+    c->tail_B = 0;
+    return backward_conv(c, B, p, g, freeze_top_n_filters, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int explainn_input_flags(explainn_ctx* c, int* flags_host, void* stream) {

@@ -28,6 +28,7 @@ struct explainn_ctx {
     hipEvent_t ev_fork, ev_join;
     // ---- state of the step in flight ----
     int fwd_B;            // batch of the last train forward (0 = none)
+    int tail_B;           // batch of a train_step_fc whose train_step_conv is still due (0 = none)
     int fwd_drop;         // dropout was active
     float fwd_scale;      // 1/(1-p)
     // ---- device scratch ----

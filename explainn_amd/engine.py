@@ -44,10 +44,19 @@ class StepEngine:
         for p, v in zip(self.params, self.views):
             p.grad = v
 
-    def step(self, x, y, seed=None, freeze_top_n_filters=0):
+    @property
+    def conv_grad_elements(self):
+        """Leading elements of flat_grad that the last part of the backward writes (conv_w, conv_b,
+        bn1_w, bn1_b): the `split` of parallel.GradAllReduce."""
+        return sum(p.numel() for p in self.params[:4])
+
+    def step(self, x, y, seed=None, freeze_top_n_filters=0, grad_sync=None):
         """x (B,4,L) fp32 one-hot -- or base codes (uint8 (B,L) / architectures.BaseCodes) -- and
         y (B,T) fp32, both resident on the device.  Enqueues one train-mode forward + loss +
-        backward; returns (logits view, loss tensor) without syncing."""
+        backward; returns (logits view, loss tensor) without syncing.  With grad_sync (a
+        parallel.GradAllReduce over flat_grad) the step also averages the gradients across ranks:
+        the all-reduce of the FC/head gradients is enqueued as soon as they are final and runs
+        under the filter-bank backward (explainn_train_step_fc / _conv)."""
         B = x.shape[0]
         if seed is None:
             self.step_no += 1
@@ -55,10 +64,22 @@ class StepEngine:
         m = self.model
         if not (torch.is_tensor(x) and x.dtype == torch.float32):
             x = m._prep_input(x, self.dev)
-        _lib.check(self.ctx.lib.explainn_train_step(
-            self.ctx.handle, m._x_ptr(self.ctx, x, self.dev), y.data_ptr(), B, C.byref(self.ps), C.byref(self.gs),
-            self.loss_kind, float(m.dropout_p), C.c_uint64(seed), int(freeze_top_n_filters),
-            self.logits.data_ptr(), self.loss.data_ptr(),
-            C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
+        stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+        xp = m._x_ptr(self.ctx, x, self.dev)
+        if grad_sync is None:
+            _lib.check(self.ctx.lib.explainn_train_step(
+                self.ctx.handle, xp, y.data_ptr(), B, C.byref(self.ps), C.byref(self.gs),
+                self.loss_kind, float(m.dropout_p), C.c_uint64(seed), int(freeze_top_n_filters),
+                self.logits.data_ptr(), self.loss.data_ptr(), stream))
+        else:
+            _lib.check(self.ctx.lib.explainn_train_step_fc(
+                self.ctx.handle, xp, y.data_ptr(), B, C.byref(self.ps), C.byref(self.gs),
+                self.loss_kind, float(m.dropout_p), C.c_uint64(seed), self.logits.data_ptr(),
+                self.loss.data_ptr(), stream))
+            work = grad_sync.start_tail()
+            _lib.check(self.ctx.lib.explainn_train_step_conv(
+                self.ctx.handle, B, C.byref(self.ps), C.byref(self.gs), int(freeze_top_n_filters),
+                stream))
+            grad_sync.finish(work)
         m._rt.token += 1
         return self.logits[:B], self.loss

@@ -41,11 +41,18 @@ class GradAllReduce:
     """Averages one flat gradient buffer across ranks: a single collective per step.  At C2 the
     buffer is 3.7 MB; RCCL picks its own algorithm."""
 
-    def __init__(self, flat):
+    def __init__(self, flat, split=0, force=False):
+        """split: number of leading elements (conv_w, conv_b, bn1_w, bn1_b in explainn_grads order)
+        that only the last part of the backward produces; everything behind it is final earlier and
+        can be reduced while that part still runs (`start_tail` / `finish`, used by StepEngine)."""
         self.flat = flat
+        self.split = int(split)
         self.n = world()
+        # force: issue the collectives even in a one-rank group (they are identities there); lets a
+        # single-GPU test drive the asynchronous RCCL path
+        self.single = self.n == 1 and not force
         self.native_avg = False
-        if self.n > 1 and dist.get_backend() == "nccl":
+        if not self.single and dist.get_backend() == "nccl":
             # ReduceOp.AVG saves the scaling pass; probe it once (all ranks take the same branch)
             try:
                 probe = torch.ones(1, device=flat.device)
@@ -54,9 +61,33 @@ class GradAllReduce:
             except Exception:
                 self.native_avg = False
 
+    def _reduce(self, t, async_op=False):
+        op = dist.ReduceOp.AVG if self.native_avg else dist.ReduceOp.SUM
+        return dist.all_reduce(t, op=op, async_op=async_op)
+
+    def start_tail(self):
+        """Enqueue the all-reduce of flat[split:] (the per-unit FC / head gradients) without making
+        the launch stream wait for it; returns the work handle for `finish`."""
+        if self.single or self.split <= 0 or self.split >= self.flat.numel():
+            return None
+        return self._reduce(self.flat[self.split:], async_op=True)
+
+    def finish(self, work):
+        """All-reduce what `start_tail` left (everything if it returned None), then make the launch
+        stream wait for both."""
+        if self.single:
+            return self.flat
+        if work is None:
+            return self()
+        self._reduce(self.flat[:self.split])
+        work.wait()
+        if not self.native_avg:
+            self.flat.div_(self.n)
+        return self.flat
+
     def __call__(self, flat=None):
         t = self.flat if flat is None else flat
-        if self.n == 1:
+        if self.single:
             return t
         if self.native_avg:
             dist.all_reduce(t, op=dist.ReduceOp.AVG)

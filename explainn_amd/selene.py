@@ -141,7 +141,8 @@ class Trainer(object):
             self._engine = StepEngine(self.model, batch, loss=kind)
             if parallel.world() > 1:
                 parallel.broadcast_parameters(self.model)
-                self._grad_sync = parallel.GradAllReduce(self._engine.flat_grad)
+                self._grad_sync = parallel.GradAllReduce(self._engine.flat_grad,
+                                                         split=self._engine.conv_grad_elements)
         return self._engine
 
     def train(self):
@@ -159,9 +160,8 @@ class Trainer(object):
             eng.refresh_params()
             _, loss = eng.step(inputs.float().contiguous(), targets.float().contiguous(),
                                seed=int(torch.randint(0, 2 ** 62, (1,)).item()),
-                               freeze_top_n_filters=self.freeze_top_n_filters)
-            if self._grad_sync is not None:
-                self._grad_sync()
+                               freeze_top_n_filters=self.freeze_top_n_filters,
+                               grad_sync=self._grad_sync)
             eng.attach_grads()
             self.optimizer.step()
             loss_value = loss.item()

@@ -118,6 +118,20 @@ int explainn_train_step(explainn_ctx* ctx, const float* x, const float* targets,
                         float dropout_p, uint64_t seed, int freeze_top_n_filters,
                         float* logits, float* loss_out, void* stream);
 
+/* The same step in the two halves a data-parallel run overlaps its gradient all-reduce with
+ * (selene/__init__.py:288-291 has no such split; the reference is single-device):
+ * explainn_train_step_fc runs forward, loss and the backward down to the per-unit FC stage -- on
+ * return (in stream order) every gradient from fc1_w to final_b, the contiguous tail of a flat
+ * buffer laid out in explainn_grads order and 97-99 % of its bytes, is final and may be handed to
+ * RCCL on another stream; explainn_train_step_conv finishes the step (conv_w, conv_b, bn1_w,
+ * bn1_b).  fc + conv == explainn_train_step, bit for bit. */
+int explainn_train_step_fc(explainn_ctx* ctx, const float* x, const float* targets, int B,
+                           const explainn_params* p, const explainn_grads* g, int loss_kind,
+                           float dropout_p, uint64_t seed, float* logits, float* loss_out,
+                           void* stream);
+int explainn_train_step_conv(explainn_ctx* ctx, int B, const explainn_params* p,
+                             const explainn_grads* g, int freeze_top_n_filters, void* stream);
+
 /* model.linears(x_rep) in eval mode (test.py:151): per-unit outputs (B,U). */
 int explainn_unit_outputs(explainn_ctx* ctx, const float* x, int B, const explainn_params* p,
                           float* outs, void* stream);

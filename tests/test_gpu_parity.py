@@ -368,3 +368,47 @@ def test_fused_adam_matches_torch_adam():
     # options the kernel does not implement fall through to torch's own step
     od = FusedAdam(pa, lr=0.003, weight_decay=0.1)
     od.step()
+
+
+# ---- the step in two halves, and the asynchronous RCCL path it exists for ------------------------
+def test_split_step_equals_fused_step_and_overlapped_allreduce():
+    import socket
+    import torch.distributed as dist
+    from explainn_amd.engine import StepEngine
+    from explainn_amd.parallel import GradAllReduce
+    g = Golden("small_u8_k19")
+    x = torch.from_numpy(g.onehot()).cuda()
+    y = torch.from_numpy(g.targets().astype(np.float32)).cuda()
+    ref = None
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        for mode in ("fused", "split"):
+            m = _model(g.sd(), g.U, g.k, g.L, g.T).train()
+            eng = StepEngine(m, g.B, loss=g.loss_kind)
+            assert eng.conv_grad_elements == g.U * 4 * g.k + 3 * g.U
+            sync = None
+            if mode == "split":
+                # one-rank group: the collectives are identities, but they are real asynchronous
+                # RCCL launches on RCCL's stream, ordered against the step by events
+                sync = GradAllReduce(eng.flat_grad, split=eng.conv_grad_elements, force=True)
+            for it in range(3):
+                logits, loss = eng.step(x, y, seed=11 + it, freeze_top_n_filters=2, grad_sync=sync)
+            torch.cuda.synchronize()
+            out = (logits.clone(), loss.clone(), eng.flat_grad.clone())
+            if ref is None:
+                ref = out
+            else:
+                for a, b in zip(ref, out):
+                    assert torch.equal(a, b)
+    finally:
+        dist.destroy_process_group()
+    # state check of the C ABI: the conv half needs its fc half
+    m = _model(g.sd(), g.U, g.k, g.L, g.T).train()
+    eng = StepEngine(m, g.B, loss=g.loss_kind)
+    from explainn_amd import _lib
+    import ctypes
+    rc = eng.ctx.lib.explainn_train_step_conv(eng.ctx.handle, g.B, ctypes.byref(eng.ps),
+                                              ctypes.byref(eng.gs), 0, None)
+    assert rc == _lib.E_STATE

@@ -30,9 +30,21 @@ def _worker(r, ws, port, q):
     same = all(torch.equal(ref[0], t) for t in ref)
     g = torch.full((10,), float(r + 1))
     GradAllReduce(g)()
+    # the two-part reduction StepEngine uses (tail first, asynchronously; head after the step)
+    g2 = torch.arange(10.) * (r + 1)
+    sync = GradAllReduce(g2, split=3)
+    work = sync.start_tail()
+    assert work is not None
+    g2[:3] += 100.0 * (r + 1)             # "the rest of the backward" writes the head meanwhile
+    sync.finish(work)
+    g3 = torch.full((4,), float(r))
+    s3 = GradAllReduce(g3, split=0)       # nothing to split off: one plain all-reduce
+    assert s3.start_tail() is None
+    s3.finish(None)
     x = torch.arange(7 * 4 * 26, dtype=torch.float32).reshape(7, 4, 26); y = torch.arange(7.)[:, None]
     xs, ys = shard_batch(x, y)
-    q.put((r, same, g.tolist(), ys.flatten().tolist(), shard_bounds(7, ws, r)))
+    q.put((r, same, g.tolist(), ys.flatten().tolist(), shard_bounds(7, ws, r), g2.tolist(),
+           g3.tolist()))
     dist.barrier(); dist.destroy_process_group()
 
 
@@ -48,3 +60,6 @@ def test_broadcast_allreduce_and_sharding_world2():
     assert res[0][2] == [1.5] * 10 and res[1][2] == [1.5] * 10, "gradient average"
     assert res[0][3] == [0., 1., 2., 3.] and res[1][3] == [4., 5., 6.]
     assert res[0][4] == (0, 4) and res[1][4] == (4, 7)
+    want = [1.5 * i + (150.0 if i < 3 else 0.0) for i in range(10)]
+    assert res[0][5] == want and res[1][5] == want, "two-part gradient average"
+    assert res[0][6] == [0.5] * 4 and res[1][6] == [0.5] * 4
