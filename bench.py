@@ -124,15 +124,22 @@ def main():
     if world > 1:
         broadcast_parameters(model)
     eng = StepEngine(model, B_PER_GPU, loss="binary")
-    # the all-reduce of the FC/head gradients (97 % of the buffer) starts as soon as they are final
-    # and runs under the filter-bank backward; the small remainder follows the step
     sync = (GradAllReduce(eng.flat_grad, split=eng.conv_grad_elements, force=force_sync)
             if dist is not None else None)
+    # Default: ONE all-reduce of the flat buffer after the step.  EXPLAINN_BENCH_OVERLAP=1 switches to
+    # the two-part reduction (FC/head gradients reduced under the filter-bank backward); in the
+    # one-rank rehearsal its second collective cost more than the overlap saved
+    overlap = os.environ.get("EXPLAINN_BENCH_OVERLAP", "0") == "1"
     P = eng.flat_grad.numel()
     x, y = synthetic_batch(B_PER_GPU, 1000 + rank, dev)
 
     def one_step(i):
-        eng.step(x, y, seed=(rank << 40) + i + 1, grad_sync=sync)
+        if overlap:
+            eng.step(x, y, seed=(rank << 40) + i + 1, grad_sync=sync)
+        else:
+            eng.step(x, y, seed=(rank << 40) + i + 1)
+            if sync is not None:
+                sync()
 
     def fence():
         if dist is not None:

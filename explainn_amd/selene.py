@@ -160,8 +160,9 @@ class Trainer(object):
             eng.refresh_params()
             _, loss = eng.step(inputs.float().contiguous(), targets.float().contiguous(),
                                seed=int(torch.randint(0, 2 ** 62, (1,)).item()),
-                               freeze_top_n_filters=self.freeze_top_n_filters,
-                               grad_sync=self._grad_sync)
+                               freeze_top_n_filters=self.freeze_top_n_filters)
+            if self._grad_sync is not None:
+                self._grad_sync()       # one all-reduce of the flat buffer
             eng.attach_grads()
             self.optimizer.step()
             loss_value = loss.item()
