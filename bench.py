@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--skip-optimizer", action="store_true",
+                    help="skip the secondary fwd+bwd+Adam timing (profiling runs: one leg only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -160,19 +162,21 @@ def main():
     gpu_ms = ev0.elapsed_time(ev1)       # HIP events on the launch stream (torch current stream)
     # secondary figure ("report with and without the optimiser step"): the same step
     # followed by the fused Adam update, timed the same way; not part of `value`
-    from explainn_amd import get_optimizer
-    opt = get_optimizer(model.parameters(), lr=0.003)
-    eng.attach_grads()
-    for i in range(3):
-        one_step(i)
-        opt.step()
-    fence()
-    t1 = time.perf_counter()
-    for i in range(args.steps):
-        one_step(args.warmup + args.steps + i)
-        opt.step()
-    fence()
-    wall_opt = time.perf_counter() - t1
+    wall_opt = 0.0
+    if not args.skip_optimizer:
+        from explainn_amd import get_optimizer
+        opt = get_optimizer(model.parameters(), lr=0.003)
+        eng.attach_grads()
+        for i in range(3):
+            one_step(i)
+            opt.step()
+        fence()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            one_step(args.warmup + args.steps + i)
+            opt.step()
+        fence()
+        wall_opt = time.perf_counter() - t1
     flags = model.input_flags()
     assert flags == 0, "synthetic input flagged as not one-hot"
     assert torch.isfinite(eng.loss).all() and torch.isfinite(eng.flat_grad).all()
@@ -207,9 +211,10 @@ def main():
                          "algorithmic_bytes_per_step": alg,
                          "gpu_ms_per_step_hip_events": round(step_gpu_s * 1e3, 4)},
         }
-        out["with_optimizer"] = {"ms_per_step": round(wall_opt / args.steps * 1e3, 4),
-                                 "value": round(seqs / wall_opt, 1), "unit": "sequences/s",
-                                 "optimizer": "Adam(lr=0.003), one fused launch (csrc/adam.hip)"}
+        out["with_optimizer"] = None if args.skip_optimizer else {
+            "ms_per_step": round(wall_opt / args.steps * 1e3, 4),
+            "value": round(seqs / wall_opt, 1), "unit": "sequences/s",
+            "optimizer": "Adam(lr=0.003), one fused launch (csrc/adam.hip)"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         else:

@@ -440,16 +440,17 @@ __global__ __launch_bounds__(64, 5) void conv_bwd_kernel(const float* __restrict
 #pragma unroll
     for (int j = 0; j < K; ++j) { a1[j] = 0.f; a2[j] = 0.f; a3[j] = 0.f; nacc[j] = 0.f; }
     float tot = 0.f;
+    const float* __restrict__ dyu = dy + (size_t)u * n * Bs;
+    const uint8_t* __restrict__ idxu = idx + (size_t)u * n * Bs;
     // dy / idx for two windows are requested together (more would cost the 5th wave per SIMD)
     for (int wb = 0; wb < n; wb += 2) {
         float dyq[2];
         int psq[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int w = min(wb + q, n - 1);
-            const size_t off = ((size_t)u * n + w) * Bs + b;
-            dyq[q] = dy[off];                          // unconditional (w is clamped)
-            psq[q] = (int)idx[off];
+            const int off = min(wb + q, n - 1) * Bs + b;   // 32-bit lane offset from a uniform base
+            dyq[q] = dyu[off];                         // unconditional (w is clamped)
+            psq[q] = (int)idxu[off];
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) { KEEP(dyq[q]); KEEP(psq[q]); }

@@ -326,6 +326,10 @@ __global__ __launch_bounds__(256, (NQ <= 32 ? 5 : 1)) void passB_kernel(
     for (int i = tid; i < NWT * 32; i += 256) k0s[i] = (i < NS) ? k0p[(size_t)u * NS + i] : 0.f;
     __syncthreads();
     STAMP(1);
+    // wave-uniform bases + 32-bit lane offsets (saddr addressing): 64-bit per-row addresses were
+    // hoisted out of the tile loop and spilled (200 B/lane of scratch at the 5-waves/SIMD budget)
+    const float* __restrict__ eu = ext + (size_t)u * n * Bs;
+    float* __restrict__ dyu = dy + (size_t)u * n * Bs;
     const float a1 = alpha[u], s1 = shift[u];
     const float mu = (float)mug[u];
     const float isg = (float)(1.0 / sig1[u]);
@@ -336,7 +340,7 @@ __global__ __launch_bounds__(256, (NQ <= 32 ? 5 : 1)) void passB_kernel(
         const bool live = b < B;
         float nqf[NKS];
 #pragma unroll
-        for (int s = 0; s < NKS; ++s) nqf[s] = ext[((size_t)u * n + min(2 * s + kk, n - 1)) * Bs + b];
+        for (int s = 0; s < NKS; ++s) nqf[s] = eu[min(2 * s + kk, n - 1) * Bs + b];
 #pragma unroll
         for (int s = 0; s < NKS; ++s) KEEP(nqf[s]);
 #pragma unroll
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(256, (NQ <= 32 ? 5 : 1)) void passB_kernel(
                 for (int g8 = 0; g8 < 8; ++g8) {
                     const int g = h * 8 + g8;
                     const int w = wt * 32 + (g & 3) + 8 * (g >> 2) + 4 * kk;
-                    exv[g8] = ext[((size_t)u * n + min(w, n - 1)) * Bs + b];
+                    exv[g8] = eu[min(w, n - 1) * Bs + b];
                 }
 #pragma unroll
                 for (int g8 = 0; g8 < 8; ++g8) KEEP(exv[g8]);
@@ -385,7 +389,7 @@ __global__ __launch_bounds__(256, (NQ <= 32 ? 5 : 1)) void passB_kernel(
                     const float dyv = (live && w < n) ? acc[g] * qv : 0.f;
                     sA += dyv;
                     sB = fmaf(dyv, (ex - mu) * isg, sB);
-                    if (w < n) dy[((size_t)u * n + w) * Bs + b] = dyv;
+                    if (w < n) dyu[w * Bs + b] = dyv;
                 }
             }
         }

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""HBM-side bytes per training step from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; they do
+not fit one pass -- MI355X_MICROARCH.md, counter table).  Counter values are KiB per dispatch.
+
+    python tools/traffic.py <fetch_dir> <write_dir> <out.json> [round-tag]
+
+Per step = sum over this library's kernels / number of steps (= launches of pack_onehot_kernel).
+gfx950 correction (same guide, HBM section): FETCH_SIZE tallies 128-B requests at 64 B -> x2;
+WRITE_SIZE is exact for wide streaming stores."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def per_kernel(path, counter):
+    f = glob.glob(path + "/*/*counter_collection.csv")[0]
+    tot, calls = collections.defaultdict(float), collections.defaultdict(int)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if name.startswith(("__amd", "at::")):
+            continue
+        tot[name] += float(r["Counter_Value"]) * 1024.0
+        calls[name] += 1
+    return tot, calls
+
+
+def main():
+    fetch_dir, write_dir, out = sys.argv[1:4]
+    tag = sys.argv[4] if len(sys.argv) > 4 else "r01"
+    ft, fc = per_kernel(fetch_dir, "FETCH_SIZE")
+    wt, wc = per_kernel(write_dir, "WRITE_SIZE")
+    steps = max(v for k, v in fc.items() if k.startswith("pack_onehot"))
+    rows = {}
+    for k in sorted(set(ft) | set(wt), key=lambda k: -(2 * ft.get(k, 0) + wt.get(k, 0))):
+        rows[k] = {"fetch_raw_MB": round(ft.get(k, 0) / steps / 1e6, 3),
+                   "write_MB": round(wt.get(k, 0) / max(wc.get(k, steps) and steps, 1) / 1e6, 3)}
+    fetch_raw = sum(ft.values()) / steps
+    write = sum(wt.values()) / steps
+    res = {
+        "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over "
+                  "`python3 bench.py --no-cpu-baseline --skip-optimizer --steps 5 --warmup 2`, all launches of this "
+                  "library, divided by the number of steps; profiles/%s_pmc_*.csv" % tag,
+        "steps_profiled": steps,
+        "fetch_raw_MB_per_step": round(fetch_raw / 1e6, 1),
+        "write_MB_per_step": round(write / 1e6, 1),
+        "fetch_correction": "x2 (gfx950 FETCH_SIZE counts 64 B per 128-B request, MI355X_MICROARCH.md)",
+        "traffic_bytes_per_step": int(round(2 * fetch_raw + write, -5)),
+        "per_kernel_MB_per_step": rows,
+    }
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps({k: res[k] for k in ("fetch_raw_MB_per_step", "write_MB_per_step",
+                                          "traffic_bytes_per_step")}))
+
+
+if __name__ == "__main__":
+    main()
