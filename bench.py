@@ -190,6 +190,7 @@ def main():
         step_gpu_s = gpu_ms / 1e3 / args.steps
         alg = algorithmic_bytes_per_step(B_PER_GPU, P)
         achieved = alg / step_gpu_s / 1e9
+        traffic = measured_traffic() if world == 1 else None
         out = {
             "metric": "sequences/sec (fwd+bwd), 200bp one-hot, 300 units, batch 1024",
             "value": round(seqs / wall, 1), "unit": "sequences/s", "n_gpus": world,
@@ -204,7 +205,11 @@ def main():
                        "parameters": P, "parallelism": "dp%d" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                         "traffic": measured_traffic() if world == 1 else None,
+                         "traffic": traffic,
+                         # what the memory side actually moved (SURVEY 8d "hbm_measured_GBps"):
+                         # measured bytes / this run's GPU time; includes Infinity-Cache hits
+                         "measured_GBps": round(traffic / step_gpu_s / 1e9, 1) if traffic else None,
+                         "measured_frac": round(traffic / step_gpu_s / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None,
                          "traffic_note": "bytes per step, FETCH_SIZE(x2)+WRITE_SIZE from profiles/"
                                          "r01_final_traffic.json (separate rocprofv3 --pmc passes)",
                          "kernel": "train_step pipeline (all launches of one step)",

@@ -338,13 +338,14 @@ __global__ __launch_bounds__(256, (NQ <= 32 ? 5 : 1)) void passB_kernel(
         if (bt * 32 >= B) break;                       // wave-uniform
         const int b = bt * 32 + rc;
         const bool live = b < B;
-        float nqf[NKS];
+        // raw pooled extremes of this lane's sequence, rows w = 2s + kk: the MFMA B operand (-q) is
+        // derived from them, and so is the epilogue's ex -- the D layout wants rows
+        // wt*32 + (g&3) + 8(g>>2) + 4kk, which this lane or its partner in the other half-wave holds
+        float exr[NKS];
 #pragma unroll
-        for (int s = 0; s < NKS; ++s) nqf[s] = eu[min(2 * s + kk, n - 1) * Bs + b];
+        for (int s = 0; s < NKS; ++s) exr[s] = eu[min(2 * s + kk, n - 1) * Bs + b];
 #pragma unroll
-        for (int s = 0; s < NKS; ++s) KEEP(nqf[s]);
-#pragma unroll
-        for (int s = 0; s < NKS; ++s) nqf[s] = (2 * s + kk < n) ? -qval(a1, nqf[s], s1) : 0.f;
+        for (int s = 0; s < NKS; ++s) KEEP(exr[s]);
         const uint4 wv = bits[(size_t)u * Bs + b];
         const float dzb = dz[(size_t)u * Bs + b];
         const uint32_t wds[4] = {wv.x, wv.y, wv.z, wv.w};
@@ -364,33 +365,32 @@ __global__ __launch_bounds__(256, (NQ <= 32 ? 5 : 1)) void passB_kernel(
                 acc = MFMA32(Tf[(wt * RKS + s) * 64 + lane], e, acc);
             }
 #pragma unroll
-            for (int s = 0; s < NKS; ++s) acc = MFMA32(Mf[(wt * NKS + s) * 64 + lane], nqf[s], acc);
+            for (int s = 0; s < NKS; ++s) {
+                const float nq = (2 * s + kk < n) ? -qval(a1, exr[s], s1) : 0.f;
+                acc = MFMA32(Mf[(wt * NKS + s) * 64 + lane], nq, acc);
+            }
             if (it == 0 && wt == 0) STAMP(3);
-            // D[w][b]: lane holds its sequence b, rows w = wt*32 + (g&3) + 8(g>>2) + 4kk
-            // epilogue in two halves of eight rows: eight unconditional loads in flight at a time
-            // (sixteen would push the kernel past the register budget of 5 waves per SIMD)
+            // D[w][b]: lane holds its sequence b, rows w = wt*32 + (g&3) + 8(g>>2) + 4kk.  Row w
+            // lives in exr[w>>1] of the half-wave with kk = w&1 = g&1: own register for that half,
+            // the partner's (lane ^ 32) for the other -- no second read of ext.
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                float exv[8];
-#pragma unroll
-                for (int g8 = 0; g8 < 8; ++g8) {
-                    const int g = h * 8 + g8;
-                    const int w = wt * 32 + (g & 3) + 8 * (g >> 2) + 4 * kk;
-                    exv[g8] = eu[min(w, n - 1) * Bs + b];
+            for (int g = 0; g < 16; ++g) {
+                const int wbase = wt * 32 + (g & 3) + 8 * (g >> 2);     // row of the kk = 0 half
+                const int s0 = min(wbase >> 1, NKS - 1), s1i = min((wbase + 4) >> 1, NKS - 1);
+                float ex;
+                if ((g & 1) == 0) {          // even rows are held by kk = 0 lanes
+                    const float fromPartner = __shfl_xor(exr[s1i], 32, 64);
+                    ex = kk ? fromPartner : exr[s0];
+                } else {                     // odd rows by kk = 1 lanes
+                    const float fromPartner = __shfl_xor(exr[s0], 32, 64);
+                    ex = kk ? exr[s1i] : fromPartner;
                 }
-#pragma unroll
-                for (int g8 = 0; g8 < 8; ++g8) KEEP(exv[g8]);
-#pragma unroll
-                for (int g8 = 0; g8 < 8; ++g8) {
-                    const int g = h * 8 + g8;
-                    const int w = wt * 32 + (g & 3) + 8 * (g >> 2) + 4 * kk;
-                    const float ex = exv[g8];
-                    const float qv = qval(a1, ex, s1);
-                    const float dyv = (live && w < n) ? acc[g] * qv : 0.f;
-                    sA += dyv;
-                    sB = fmaf(dyv, (ex - mu) * isg, sB);
-                    if (w < n) dyu[w * Bs + b] = dyv;
-                }
+                const int w = wbase + 4 * kk;
+                const float qv = qval(a1, ex, s1);
+                const float dyv = (live && w < n) ? acc[g] * qv : 0.f;
+                sA += dyv;
+                sB = fmaf(dyv, (ex - mu) * isg, sB);
+                if (w < n) dyu[w * Bs + b] = dyv;
             }
         }
         if (it == 0) STAMP(4);
