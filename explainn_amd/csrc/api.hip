@@ -49,7 +49,6 @@ void carve(explainn_ctx* c, Carver& cv) {
     cv.take(&c->lut, (int64_t)(c->U4 / 2) * ((c->k + 1) / 2) * 32);
     cv.take(&c->ext, U4 * n * Bs);
     cv.take(&c->idx, U4 * n * Bs);
-    cv.take(&c->qbw, 64);                              // (sequence-major q copy: no longer used)
     cv.take(&c->qs0, U * NS);
     cv.take(&c->qS1p, U * c->QCH * NS);
     cv.take(&c->qS2p, U * c->QCH * NS * NS);
@@ -68,8 +67,6 @@ void carve(explainn_ctx* c, Carver& cv) {
     cv.take(&c->EQp, U * c->ACH * FC_H * NS);
     cv.take(&c->Sep, U * c->ACH * FC_H);
     cv.take(&c->EQs, U * FC_H * NS);
-    cv.take(&c->md2, U * FC_H);
-    cv.take(&c->md2h, U * FC_H);
     cv.take(&c->Tt, (U * FC_H + 2) * NS);
     cv.take(&c->M, (U * NS + 2) * NS);
     cv.take(&c->Ttf, U * ((c->NQ + 31) / 32) * (FC_H / 2) * 64);

@@ -1,118 +1,18 @@
 // Backward "small algebra" and the filter-gradient scatter.
 //
-//   mid1      per unit: sum passA's chunk partials; gradients of FC2 weights and BN2 affine
-//             parameters; the two BN2-backward means md2, md2h.
-//   mid2a     per unit: gradient of FC1 weights (BN2 backward folded in through the q covariance)
-//             and the table T[r][w] passB streams.
-//   mid2b     per unit: the n x n matrix M and vector k0' that carry the BN2-backward mean terms
-//             into dq.
+//   mid_fused / mid_big   per unit: sum passA's chunk partials; gradients of the FC2 weights and
+//             the BN2 affine parameters; the gradient of the FC1 weights (BN2 backward folded in
+//             through V1.C, which prep2 left in VC); the tables passB consumes: T[r][w], the n x n
+//             matrix M and the vector k0' that carry the BN2-backward mean terms into dq.
+//             n <= 72: everything in LDS, fp64.  n > 72: M on the fp32 MFMA, EQ through global.
 //   conv_bwd  sparse term of the filter gradient: every pooling window sends dy to the one position
 //             that won the max, so dW gets dy added at (base at p*+j, tap j) for the k taps.
-//             Lane = sequence, private LDS accumulators [k][4] per lane (ds_add_f32, conflict-free
-//             by an odd row stride), bases from the 2-bit packed codes with a 64-bit funnel window.
+//             Lane = sequence, register accumulators per tap, bases from the 2-bit packed codes
+//             through a 64-bit funnel window.
 //   fin_bwd   per unit: BN1 backward closed form -> dW, d gamma1, d beta1.
 #include "common.h"
 
-__global__ __launch_bounds__(128) void mid1_kernel(
-    const float* __restrict__ EQp, const float* __restrict__ Sep, const float* __restrict__ A2,
-    const float* __restrict__ sh2, const float* __restrict__ sig2, const float* __restrict__ fc1_w,
-    const float* __restrict__ fc2_w, const double* __restrict__ qbar, float* __restrict__ EQs,
-    float* __restrict__ md2, float* __restrict__ md2h, float* __restrict__ g_fc2_w,
-    float* __restrict__ g_bn2_w, float* __restrict__ g_bn2_b, float* __restrict__ g_fc1_b, int n,
-    int NS, int B, int ACH, float scale) {
-    const int u = blockIdx.x, r = threadIdx.x;
-    if (r >= FC_H) return;
-    const int ch = u * FC_H + r;
-    double se = 0;
-    for (int c = 0; c < ACH; ++c) se += (double)Sep[((size_t)u * ACH + c) * FC_H + r];
-    double sAE = 0, sVE = 0;
-    const float* v1 = fc1_w + (size_t)ch * n;
-    for (int w = 0; w < n; ++w) {
-        double eq = 0;
-        for (int c = 0; c < ACH; ++c)
-            eq += (double)EQp[(((size_t)u * ACH + c) * FC_H + r) * NS + w];
-        EQs[(size_t)ch * NS + w] = (float)eq;
-        sAE = fma((double)A2[(size_t)ch * NS + w], eq, sAE);
-        sVE = fma((double)v1[w], eq - se * qbar[(size_t)u * NS + w], sVE);
-    }
-    const double sc = (double)scale, v2 = (double)fc2_w[ch], sg = (double)sig2[ch];
-    g_fc2_w[ch] = (float)(sc * (sAE + (double)sh2[ch] * se));
-    const double db2 = sc * v2 * se;
-    const double dg2 = sc * v2 / sg * sVE;
-    g_bn2_b[ch] = (float)db2;
-    g_bn2_w[ch] = (float)dg2;
-    g_fc1_b[ch] = 0.f;
-    md2[ch] = (float)(db2 / (double)B);
-    md2h[ch] = (float)(dg2 / (double)B);
-}
-
-__global__ __launch_bounds__(256) void mid2a_kernel(
-    const float* __restrict__ EQs, const float* __restrict__ A2, const float* __restrict__ sig2,
-    const float* __restrict__ fc1_w, const float* __restrict__ fc2_w, const float* __restrict__ g2,
-    const double* __restrict__ qbar, const float* __restrict__ C, const float* __restrict__ md2,
-    const float* __restrict__ md2h, float* __restrict__ Tt, float* __restrict__ Ttf,
-    float* __restrict__ g_fc1_w, int n, int NS, int NWT, int B, float scale) {
-    const int u = blockIdx.x;
-    const float* Cu = C + (size_t)u * NS * NS;
-    for (int e = threadIdx.x; e < FC_H * NS; e += 256) {
-        const int r = e / NS, w = e % NS, ch = u * FC_H + r;
-        const double sv = (double)scale * (double)fc2_w[ch];
-        const float tval = (float)(sv * (double)A2[(size_t)ch * NS + w]);
-        Tt[(size_t)ch * NS + w] = tval;
-        Ttf[(size_t)u * NWT * (FC_H / 2) * 64 + ((size_t)(w >> 5) * (FC_H / 2) + (r >> 1)) * 64 + (r & 1) * 32 + (w & 31)] = tval;
-        if (w < n) {
-            const float* v1 = fc1_w + (size_t)ch * n;
-            double hq = 0;
-            for (int v = 0; v < n; ++v) hq = fma((double)v1[v], (double)Cu[(size_t)v * NS + w], hq);
-            const double sg = (double)sig2[ch];
-            hq *= (double)B / sg;
-            const double val = ((double)g2[ch] / sg) *
-                               (sv * (double)EQs[(size_t)ch * NS + w] -
-                                (double)md2[ch] * (double)B * qbar[(size_t)u * NS + w] -
-                                (double)md2h[ch] * hq);
-            g_fc1_w[(size_t)ch * n + w] = (float)val;
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void mid2b_kernel(
-    const float* __restrict__ A2, const float* __restrict__ sig2, const float* __restrict__ fc1_w,
-    const double* __restrict__ qbar, const float* __restrict__ md2, const float* __restrict__ md2h,
-    float* __restrict__ M, float* __restrict__ Mff, float* __restrict__ k0p, int n, int NS, int NWT,
-    int NKS) {
-    extern __shared__ float Msm[];            // [n][n]
-    const int u = blockIdx.x;
-    for (int e = threadIdx.x; e < NS * NS; e += 256) {
-        const int v = e / NS, w = e % NS;
-        double acc = 0;
-        if (v < n && w < n) {
-            for (int r = 0; r < FC_H; ++r) {
-                const int ch = u * FC_H + r;
-                acc = fma((double)md2h[ch] / (double)sig2[ch] * (double)fc1_w[(size_t)ch * n + v],
-                          (double)A2[(size_t)ch * NS + w], acc);
-            }
-            Msm[v * n + w] = (float)acc;
-        }
-        M[(size_t)u * NS * NS + e] = (float)acc;
-        if ((v >> 1) < NKS)
-            Mff[(size_t)u * NWT * NKS * 64 + ((size_t)(w >> 5) * NKS + (v >> 1)) * 64 + (v & 1) * 32 + (w & 31)] = (float)acc;
-    }
-    __syncthreads();
-    for (int w = threadIdx.x; w < NS; w += 256) {
-        double k0 = 0;
-        if (w < n) {
-            for (int r = 0; r < FC_H; ++r) {
-                const int ch = u * FC_H + r;
-                k0 = fma((double)A2[(size_t)ch * NS + w], (double)md2[ch], k0);
-            }
-            for (int v = 0; v < n; ++v) k0 -= qbar[(size_t)u * NS + v] * (double)Msm[v * n + w];
-        }
-        k0p[(size_t)u * NS + w] = (float)k0;
-    }
-}
-
-
-// Fused mid1+mid2a+mid2b for n <= 72: one 1024-thread block per unit with V1, A2, EQ, C and M
+// n <= 72: one 1024-thread block per unit with V1, A2, EQ and M
 // staged in LDS, so every inner loop reads LDS instead of chasing dependent global loads.
 __global__ __launch_bounds__(1024) void mid_fused_kernel(
     const float* __restrict__ EQp, const float* __restrict__ Sep, const float* __restrict__ A2,
@@ -603,10 +503,6 @@ int launch_fin_bwd(explainn_ctx* c, const explainn_params* p, const explainn_gra
 }
 
 int bwd_configure(explainn_ctx* c) {
-    const size_t sm = (size_t)c->n * c->n * sizeof(float);
-    if (sm > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mid2b_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
     if (c->n > 72)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mid_big_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,

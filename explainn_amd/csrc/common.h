@@ -49,7 +49,6 @@ struct explainn_ctx {
     float* lut;           // [U4/2][ceil(k/2)][16] float2: dinucleotide tables per unit pair
     float* ext;           // [U4][n][Bs]      pooled extreme of the raw gather sum
     uint8_t* idx;         // [U4][n][Bs]      argmax offset 0..6 inside the pooling window
-    float* qbw;           // [U][Bs][NS]      q = exp(alpha*ext+shift), sequence-major
     float* qs0;           // [U][NS]          shift for the q moments (q of sequence 0)
     float* qS1p;          // [U][QCH][NS]
     float* qS2p;          // [U][QCH][NS][NS]
@@ -69,8 +68,6 @@ struct explainn_ctx {
     float* EQp;           // [U][ACH][100][NS]
     float* Sep;           // [U][ACH][100]
     float* EQs;           // [U][100][NS]
-    float* md2;           // [U][100]
-    float* md2h;          // [U][100]
     float* Tt;            // [U][100][NS]
     float* Ttf;           // [U][NWT][50][64]  T in MFMA A-fragment order (passB copies it to LDS)
     float* Mff;           // [U][NWT][NKS][64] M in MFMA A-fragment order
