@@ -325,15 +325,18 @@ __global__ __launch_bounds__(64, 5) void conv_bwd_kernel(const float* __restrict
     // serialise per lane on gfx950 and LDS read-modify-write chains were latency-bound,
     // profiles/r01_c); <= 102 VGPRs and 7 KB of LDS keep 5 waves per SIMD, i.e. the whole grid
     // resident in one round at C2.
-    extern __shared__ uint32_t smem[];        // pk2 tile [PW][64], nmask tile [NW][64]
+    // The packed codes are staged per chunk of CBW pooling windows (the positions a chunk touches
+    // span CBW*7 + K - 1 bases): a fixed ~7 KB of LDS per wave whatever the sequence length, so the
+    // 5 waves/SIMD hold for L = 1000 too (staging the whole sequence cost 26 KB there and left
+    // 1.5 waves/SIMD).  Columns are lane-private: no barrier between chunks.
+    constexpr int CBW = 32;
+    constexpr int PWC = ((POOLW * CBW + K + 15) >> 4) + 2, NWC = ((POOLW * CBW + K + 31) >> 5) + 2;
+    extern __shared__ uint32_t smem[];        // pk2 chunk [PWC][64], nmask chunk [NWC][64]
     uint32_t* pks = smem;
-    uint32_t* nms = smem + (size_t)PW * 64;
+    uint32_t* nms = smem + (size_t)PWC * 64;
     const int lane = threadIdx.x, tile = blockIdx.x, u = blockIdx.y;
     const int b = tile * 64 + lane;
     STAMP(0);
-    stage_column(pks + lane, pk2 + b, PW, Bs);
-    stage_column(nms + lane, nmask + b, NW, Bs);
-    STAMP(1);
     constexpr uint32_t KMASK = (K >= 32) ? 0xffffffffu : ((1u << K) - 1u);
     float a1[K], a2[K], a3[K];
     float nacc[K];                                     // wave-uniform (SGPRs)
@@ -342,51 +345,59 @@ __global__ __launch_bounds__(64, 5) void conv_bwd_kernel(const float* __restrict
     float tot = 0.f;
     const float* __restrict__ dyu = dy + (size_t)u * n * Bs;
     const uint8_t* __restrict__ idxu = idx + (size_t)u * n * Bs;
-    // dy / idx for two windows are requested together (more would cost the 5th wave per SIMD)
-    for (int wb = 0; wb < n; wb += 2) {
-        float dyq[2];
-        int psq[2];
+    for (int wc = 0; wc < n; wc += CBW) {
+        // chunk origin in words: POOLW*CBW = 224 positions = 14 code words = 7 mask words
+        const int w_lo = (POOLW * wc) >> 4, n_lo = (POOLW * wc) >> 5;
+        stage_column(pks + lane, pk2 + (size_t)w_lo * Bs + b, min(PWC, PW - w_lo), Bs);
+        stage_column(nms + lane, nmask + (size_t)n_lo * Bs + b, min(NWC, NW - n_lo), Bs);
+        if (wc == 0) STAMP(1);
+        const int wend = min(wc + CBW, n);
+        // dy / idx for two windows are requested together (more would cost the 5th wave per SIMD)
+        for (int wb = wc; wb < wend; wb += 2) {
+            float dyq[2];
+            int psq[2];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int off = min(wb + q, n - 1) * Bs + b;   // 32-bit lane offset from a uniform base
-            dyq[q] = dyu[off];                         // unconditional (w is clamped)
-            psq[q] = (int)idxu[off];
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) { KEEP(dyq[q]); KEEP(psq[q]); }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            dyq[q] = (wb + q < n) ? dyq[q] : 0.f;
-            psq[q] += POOLW * min(wb + q, n - 1);
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const float dyv = dyq[q];                  // 0 for windows past the end
-            const int ps = psq[q];
-            const int w0 = ps >> 4, sh = (ps & 15) * 2;
-            const uint32_t c0 = pks[w0 * 64 + lane], c1 = pks[(w0 + 1) * 64 + lane],
-                           c2 = pks[(w0 + 2) * 64 + lane];
-            const uint32_t lo = __funnelshift_r(c0, c1, sh), hi = __funnelshift_r(c1, c2, sh);
-            const int n0 = ps >> 5, nsh = ps & 31;
-            const uint32_t nm = __funnelshift_r(nms[n0 * 64 + lane], nms[(n0 + 1) * 64 + lane], nsh) & KMASK;
-#pragma unroll
-            for (int j = 0; j < K; ++j) {
-                const uint32_t code = (j < 16 ? (lo >> (2 * j)) : (hi >> (2 * (j - 16)))) & 3u;
-                a1[j] += (code == 1u) ? dyv : 0.f;
-                a2[j] += (code == 2u) ? dyv : 0.f;
-                a3[j] += (code == 3u) ? dyv : 0.f;
+            for (int q = 0; q < 2; ++q) {
+                const int off = min(wb + q, wend - 1) * Bs + b;   // 32-bit lane offset, uniform base
+                dyq[q] = dyu[off];                         // unconditional (w is clamped)
+                psq[q] = (int)idxu[off];
             }
-            if (__any(nm != 0u)) {
-                // rare: some lane's window holds an N.  N is packed as 'C', so its dy went into
-                // a1[j] and into tot: base A is already right (tot - a1 cancels it), and the C
-                // bucket is corrected by the wave-wide sum of those dy, kept in scalar registers
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { KEEP(dyq[q]); KEEP(psq[q]); }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                dyq[q] = (wb + q < wend) ? dyq[q] : 0.f;
+                psq[q] += POOLW * min(wb + q, wend - 1);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float dyv = dyq[q];                  // 0 for windows past the end
+                const int ps = psq[q];
+                const int w0 = (ps >> 4) - w_lo, sh = (ps & 15) * 2;
+                const uint32_t c0 = pks[w0 * 64 + lane], c1 = pks[(w0 + 1) * 64 + lane],
+                               c2 = pks[(w0 + 2) * 64 + lane];
+                const uint32_t lo = __funnelshift_r(c0, c1, sh), hi = __funnelshift_r(c1, c2, sh);
+                const int n0 = (ps >> 5) - n_lo, nsh = ps & 31;
+                const uint32_t nm = __funnelshift_r(nms[n0 * 64 + lane], nms[(n0 + 1) * 64 + lane], nsh) & KMASK;
 #pragma unroll
                 for (int j = 0; j < K; ++j) {
-                    const float dn = wave_sum(((nm >> j) & 1u) ? dyv : 0.f);
-                    nacc[j] += __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, dn)));
+                    const uint32_t code = (j < 16 ? (lo >> (2 * j)) : (hi >> (2 * (j - 16)))) & 3u;
+                    a1[j] += (code == 1u) ? dyv : 0.f;
+                    a2[j] += (code == 2u) ? dyv : 0.f;
+                    a3[j] += (code == 3u) ? dyv : 0.f;
                 }
+                if (__any(nm != 0u)) {
+                    // rare: some lane's window holds an N.  N is packed as 'C', so its dy went into
+                    // a1[j] and into tot: base A is already right (tot - a1 cancels it), and the C
+                    // bucket is corrected by the wave-wide sum of those dy, kept in scalar registers
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        const float dn = wave_sum(((nm >> j) & 1u) ? dyv : 0.f);
+                        nacc[j] += __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, dn)));
+                    }
+                }
+                tot += dyv;
             }
-            tot += dyv;
         }
     }
     STAMP(2);
@@ -438,7 +449,9 @@ __global__ __launch_bounds__(64, 5) void conv_bwd_kernel(const float* __restrict
 
 int launch_conv_bwd(explainn_ctx* c, int B, hipStream_t s) {
     const dim3 grid((B + 63) / 64, c->U);
-    size_t sm = (size_t)(c->PW + c->NW) * 64 * sizeof(uint32_t);
+    // chunk tiles (see the kernel: [PWC + NWC][64] words) or the [k][65] reduction tile
+    const int pwc = ((POOLW * 32 + c->k + 15) >> 4) + 2, nwc = ((POOLW * 32 + c->k + 31) >> 5) + 2;
+    size_t sm = (size_t)(pwc + nwc) * 64 * sizeof(uint32_t);
     const size_t red_bytes = (size_t)c->k * 65 * sizeof(float);
     if (sm < red_bytes) sm = red_bytes;
 #define CALL(KK)                                                                               \
