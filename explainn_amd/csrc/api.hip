@@ -77,6 +77,8 @@ void carve(explainn_ctx* c, Carver& cv) {
     cv.take(&c->Dspp, U * (Bs / 64) * K4);
     cv.take(&c->dlogits, (int64_t)c->maxB * c->T);
     cv.take(&c->flags, 64);
+    cv.take(&c->dlT, (int64_t)c->T * Bs);
+    cv.take(&c->lossp, 64);
     cv.take(&c->site_cnt, U4 * Bs);
     cv.take(&c->site_off, U4 * Bs);
     cv.off = (cv.off + 255) & ~int64_t(255);

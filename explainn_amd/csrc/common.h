@@ -8,6 +8,7 @@
 #include "../../include/explainn_hip.h"
 
 #define FC_H 100          // hidden width of the per-unit FC (architectures/__init__.py:86)
+#define HEAD_GEMM_MIN_T 8   // more tasks than this: combiner forward/backward as MFMA GEMMs (head.hip)
 #define POOLW 7           // MaxPool1d(7,7)        (architectures/__init__.py:81)
 #define BN_EPS_D 1e-5     // architectures/__init__.py:79,90,99
 #define BN_MOM_D 0.1
@@ -77,6 +78,8 @@ struct explainn_ctx {
     float* S12p;          // [U][Bs/32][2]    per 32-sequence tile: sum dy, sum dy*chat
     float* Dspp;          // [U][Bs/64][4k]
     float* dlogits;       // [maxB][T]         (train_step only)
+    float* dlT;           // [T][Bs]   d loss / d logits, task-major (head GEMMs, T > HEAD_GEMM_MIN_T)
+    double* lossp;        // [64]      per-block partial sums of the loss
     int staged_B;         // batch size of the codes explainn_stage_codes() staged, 0 = none
     int* flags;           // [1]
     int* site_cnt;        // [U4][Bs]  sites per (unit, sequence) of the current batch (filter->PWM export)

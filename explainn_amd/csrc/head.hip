@@ -3,6 +3,94 @@
 // here are (U x B) or (B x T) -- a few MB at most -- so these are plain reduction kernels.
 #include "common.h"
 
+// ---------------------------------------------------------------------------------------------
+// Many tasks (T > HEAD_GEMM_MIN_T: configs C3-C5 have 50-164): the combiner and its backward are
+// real GEMMs -- logits = o^T Wf^T (K = U), d o = dl Wf (K = T), d Wf = dl^T o^T (K = B) -- and run
+// on the fp32 MFMA.  One 256-thread block per 32x32 output tile; its four waves split K in four
+// contiguous quarters (each half-wave takes half a quarter: the order of a sum is free, so K is
+// permuted to give every lane a contiguous run), partial tiles are added in fixed order through LDS.
+// Operands are read straight from global in batches of eight per lane (they are L2-resident:
+// at most a few MB).  *_KC = "K-contiguous": element (row, k) at ptr[row*ld + k]; otherwise
+// element (k, row) at ptr[k*ld + row] (coalesced across the 32 rows of a tile).
+// ---------------------------------------------------------------------------------------------
+typedef float f32x16h __attribute__((ext_vector_type(16)));
+enum { EPI_PLAIN = 0, EPI_BIAS = 1, EPI_GW = 2 };
+
+template <bool A_KC, bool B_KC, int EPI>
+__global__ __launch_bounds__(256) void gemm32_kernel(const float* __restrict__ A, int lda,
+                                                     const float* __restrict__ Bm, int ldb,
+                                                     float* __restrict__ D, int ldd, int M, int N,
+                                                     int K, const float* __restrict__ bias,
+                                                     float* __restrict__ extra) {
+    __shared__ float part[3][16][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, rc = lane & 31, kk = lane >> 5;
+    const int tiles_n = (N + 31) >> 5;
+    const int ti = blockIdx.x / tiles_n, tj = blockIdx.x % tiles_n;
+    const int i = ti * 32 + rc, j = tj * 32 + rc;
+    const int ic = min(i, M - 1);
+    // EPI_GW: column N-1 is a virtual all-ones row of B (it yields the bias gradient)
+    const bool ones_col = EPI == EPI_GW && j == N - 1;
+    const int jc = min(j, (EPI == EPI_GW ? N - 2 : N - 1));
+    const int Kq = (K + 3) >> 2;                       // this wave's quarter [kq0, kq1)
+    const int kq0 = min(wave * Kq, K), kq1 = min(kq0 + Kq, K);
+    const int Kh = (kq1 - kq0 + 1) >> 1;               // this half-wave's run [k0, kend)
+    const int k0 = kq0 + kk * Kh, kend = min(k0 + Kh, kq1);
+    const float* ap = A_KC ? A + (size_t)ic * lda : A + ic;
+    const float* bp = B_KC ? Bm + (size_t)jc * ldb : Bm + jc;
+    f32x16h acc;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+    for (int s0 = 0; s0 < Kh; s0 += 8) {               // Kh is wave-uniform
+        float a[8], b[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int kc = min(k0 + s0 + q, K - 1);
+            a[q] = A_KC ? ap[kc] : ap[(size_t)kc * lda];
+            b[q] = B_KC ? bp[kc] : bp[(size_t)kc * ldb];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { KEEP(a[q]); KEEP(b[q]); }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const bool live = k0 + s0 + q < kend;
+            const float av = (live && i < M) ? a[q] : 0.f;
+            const float bv = (live && j < N) ? (ones_col ? 1.f : b[q]) : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) part[wave - 1][g][lane] = acc[g];
+    }
+    __syncthreads();
+    if (wave == 0 && j < N) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int row = ti * 32 + (g & 3) + 8 * (g >> 2) + 4 * kk;
+            if (row >= M) continue;
+            float v = ((acc[g] + part[0][g][lane]) + part[1][g][lane]) + part[2][g][lane];
+            if (EPI == EPI_BIAS) v += bias[j];
+            if (EPI == EPI_GW && j == N - 1) extra[row] = v;
+            else D[(size_t)row * ldd + j] = v;
+        }
+    }
+}
+
+// dlT[t][b] = dl[b][t]   (the GEMMs want the batch index contiguous)
+__global__ __launch_bounds__(256) void transpose_dl_kernel(const float* __restrict__ dl,
+                                                           float* __restrict__ dlT, int B, int T,
+                                                           int Bs) {
+    __shared__ float tile[32][33];
+    const int b0 = blockIdx.x * 32, t0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8)
+        tile[r][tx] = (b0 + r < B && t0 + tx < T) ? dl[(size_t)(b0 + r) * T + t0 + tx] : 0.f;
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (t0 + r < T && b0 + tx < B) dlT[(size_t)(t0 + r) * Bs + b0 + tx] = tile[tx][r];
+}
+
+
 __device__ __forceinline__ double block_sum_256(double v, double* red) {
     v = wave_sum_d(v);
     __syncthreads();
@@ -92,7 +180,14 @@ int launch_head_fwd(explainn_ctx* c, const explainn_params* p, int B, bool train
                            c->sig3, c->Bs, B);
         LAUNCH_CHECK();
     }
-    if (logits) {
+    if (logits && c->T > HEAD_GEMM_MIN_T) {
+        // logits[b][t] = sum_u o[u][b] Wf[t][u] + bf[t]: M = B, N = T, K = U
+        const int tiles = ((B + 31) / 32) * ((c->T + 31) / 32);
+        hipLaunchKernelGGL((gemm32_kernel<false, true, EPI_BIAS>), dim3(tiles), dim3(256), 0, s, c->o,
+                           c->Bs, p->final_w, c->U, logits, c->T, B, c->T, c->U, p->final_b,
+                           (float*)nullptr);
+        LAUNCH_CHECK();
+    } else if (logits) {
         hipLaunchKernelGGL(logits_kernel, dim3((B + 63) / 64, c->T), dim3(1024), 0, s, c->o,
                            p->final_w, p->final_b, logits, c->U, c->T, c->Bs, B);
         LAUNCH_CHECK();
@@ -105,16 +200,22 @@ int launch_head_fwd(explainn_ctx* c, const explainn_params* p, int B, bool train
     return EXPLAINN_OK;
 }
 
-// loss + dlogits, one block (B*T is at most ~1e6); fixed reduction order -> deterministic
+
+// loss + dlogits; up to LOSS_BLOCKS blocks write one partial sum each, the last block to finish adds
+// them in index order -> deterministic whatever the arrival order
+constexpr int LOSS_BLOCKS = 64;
 __global__ __launch_bounds__(1024) void loss_kernel(const float* __restrict__ logits,
                                                     const float* __restrict__ y, int kind, int N,
                                                     float* __restrict__ loss,
-                                                    float* __restrict__ dlogits) {
+                                                    float* __restrict__ dlogits,
+                                                    double* __restrict__ partial,
+                                                    int* __restrict__ counter) {
     __shared__ double red[16];
+    __shared__ int last;
     const int tid = threadIdx.x;
     const float invN = 1.0f / (float)N;
     double acc = 0;
-    for (int i = tid; i < N; i += 1024) {
+    for (int i = blockIdx.x * 1024 + tid; i < N; i += gridDim.x * 1024) {
         const float x = logits[i], t = y[i];
         float l, d;
         if (kind == EXPLAINN_LOSS_BCE_WITH_LOGITS) {
@@ -134,14 +235,26 @@ __global__ __launch_bounds__(1024) void loss_kernel(const float* __restrict__ lo
     if (tid == 0) {
         double s = 0;
         for (int i = 0; i < 16; ++i) s += red[i];
+        partial[blockIdx.x] = s;
+        __threadfence();
+        last = atomicAdd(counter, 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last && tid == 0) {
+        __threadfence();
+        double s = 0;
+        for (unsigned i = 0; i < gridDim.x; ++i) s += partial[i];
         *loss = (float)(s / (double)N);
+        *counter = 0;                                   // ready for the next launch
     }
 }
 
 int launch_loss(explainn_ctx* c, int kind, const float* logits, const float* y, int B, float* loss,
                 float* dlogits, hipStream_t s) {
-    hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(1024), 0, s, logits, y, kind, B * c->T, loss,
-                       dlogits);
+    const int N = B * c->T;
+    const int blocks = min(LOSS_BLOCKS, (N + 8191) / 8192);
+    hipLaunchKernelGGL(loss_kernel, dim3(blocks), dim3(1024), 0, s, logits, y, kind, N, loss, dlogits,
+                       c->lossp, c->flags + 1);
     LAUNCH_CHECK();
     return EXPLAINN_OK;
 }
@@ -158,8 +271,9 @@ __device__ __forceinline__ float dl_at(const float* __restrict__ dl, const float
     return 2.0f * (x - t) * invN;
 }
 
-// one block per unit: final-layer gradients, BN3 backward -> dz[u][b]
-template <bool FUSED>
+// one block per unit: final-layer gradients, BN3 backward -> dz[u][b].
+// GEMMED: d o (in dz on entry) and the final-layer gradients came from the MFMA GEMMs above.
+template <bool FUSED, bool GEMMED = false>
 __global__ __launch_bounds__(256) void head_bwd_kernel(
     const float* __restrict__ dl, const float* __restrict__ logits, const float* __restrict__ y,
     int kind, float* __restrict__ loss_out, const float* __restrict__ Wf,
@@ -176,8 +290,10 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
     double s1 = 0, s2 = 0;
     for (int b = tid; b < B; b += 256) {
         float dob = 0.f;
-        for (int t = 0; t < T; ++t)
-            dob = fmaf(dl_at<FUSED>(dl, logits, y, kind, invN, b * T + t), Wf[(size_t)t * U + u], dob);
+        if (GEMMED) dob = dzu[b];
+        else
+            for (int t = 0; t < T; ++t)
+                dob = fmaf(dl_at<FUSED>(dl, logits, y, kind, invN, b * T + t), Wf[(size_t)t * U + u], dob);
         const float d3 = ou[b] > 0.f ? dob : 0.f;
         dzu[b] = d3;
         s1 += (double)d3;
@@ -189,7 +305,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
     const float sc = g3[u] / sig3[u];
     for (int b = tid; b < B; b += 256) dzu[b] = sc * (dzu[b] - m1 - zh[b] * m2);
     if (tid == 0) { gg3[u] = (float)S2; gb3[u] = (float)S1; gc2[u] = 0.f; }
-    for (int t = 0; t < T; ++t) {
+    for (int t = 0; t < (GEMMED ? 0 : T); ++t) {
         double a = 0;
         for (int b = tid; b < B; b += 256)
             a = fma((double)dl_at<FUSED>(dl, logits, y, kind, invN, b * T + t), (double)ou[b], a);
@@ -218,6 +334,30 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
 
 int launch_head_bwd(explainn_ctx* c, const explainn_params* p, const explainn_grads* g,
                     const float* dlogits, int B, hipStream_t s) {
+    if (c->T > HEAD_GEMM_MIN_T) {
+        const int T = c->T, U = c->U;
+        hipLaunchKernelGGL(transpose_dl_kernel, dim3((B + 31) / 32, (T + 31) / 32), dim3(256), 0, s,
+                           dlogits, c->dlT, B, T, c->Bs);
+        LAUNCH_CHECK();
+        // d o[u][b] = sum_t Wf[t][u] dl[b][t]  -> dz (raw; the per-unit kernel finishes it)
+        hipLaunchKernelGGL((gemm32_kernel<false, false, EPI_PLAIN>),
+                           dim3(((U + 31) / 32) * ((B + 31) / 32)), dim3(256), 0, s, p->final_w, U,
+                           c->dlT, c->Bs, c->dz, c->Bs, U, B, T, (const float*)nullptr,
+                           (float*)nullptr);
+        LAUNCH_CHECK();
+        // d Wf[t][u] = sum_b dl[b][t] o[u][b], and d bf[t] as the virtual all-ones unit U
+        hipLaunchKernelGGL((gemm32_kernel<true, true, EPI_GW>),
+                           dim3(((T + 31) / 32) * ((U + 1 + 31) / 32)), dim3(256), 0, s, c->dlT, c->Bs,
+                           c->o, c->Bs, g->final_w, U, T, U + 1, B, (const float*)nullptr,
+                           g->final_b);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL((head_bwd_kernel<false, true>), dim3(U), dim3(256), 0, s, dlogits,
+                           (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr,
+                           p->final_w, p->bn3_w, c->o, c->zhat, c->sig3, c->dz, g->final_w,
+                           g->final_b, g->bn3_w, g->bn3_b, g->fc2_b, U, T, c->Bs, B);
+        LAUNCH_CHECK();
+        return EXPLAINN_OK;
+    }
     hipLaunchKernelGGL(head_bwd_kernel<false>, dim3(c->U), dim3(256), 0, s, dlogits,
                        (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr, p->final_w,
                        p->bn3_w, c->o, c->zhat, c->sig3, c->dz, g->final_w, g->final_b, g->bn3_w,

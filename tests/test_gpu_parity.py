@@ -176,6 +176,9 @@ def test_adam_trajectory_golden(golden):
     (9, 26, 300, 4, 200, 0.01),     # n = 39 -> bucket 40 (zero-padded weights)
     (3, 19, 1000, 2, 70, 0.0),      # n = 140 (config C4's pooled length)
     (2, 19, 600, 5, 66, 0.02),      # n = 83  -> bucket 84 (config C5's pooled length)
+    (37, 19, 61, 50, 70, 0.02),     # T = 50 (C3/C4): combiner forward/backward as MFMA GEMMs
+    (70, 9, 40, 164, 131, 0.0),     # T = 164 (C5), ragged tiles in every GEMM dimension
+    (3, 5, 33, 9, 5, 0.0),          # smallest GEMM case: one partly filled tile
 ])
 def test_train_step_vs_oracle(U, k, L, T, B, nfrac):
     sd = orc.random_state_dict(U, k, L, T, seed=U + L)
@@ -248,10 +251,13 @@ def test_builtin_dropout_rate_and_scaling():
     assert torch.equal(a, a2), "same torch seed -> same mask"
 
 
-@pytest.mark.parametrize("T,kind", [(1, "binary"), (3, "linear"), (6, "binary")])
+@pytest.mark.parametrize("T,kind", [(1, "binary"), (3, "linear"), (6, "binary"), (50, "binary"),
+                                    (21, "linear")])
 def test_step_engine_vs_oracle(T, kind):
     """explainn_train_step (what bench.py times): loss value, logits and the flat gradient buffer
-    against the oracle; T <= 4 takes the loss-fused head backward, T > 4 the separate loss kernel."""
+    against the oracle; T <= 4 takes the loss-fused head backward, T > 4 the separate loss kernel,
+    T > 8 the MFMA GEMM head (and, at T = 50 with B = 100, more than one loss block would need
+    N > 8192: covered by the C3-shaped property test)."""
     from explainn_amd.engine import StepEngine
     U, k, L, B = 6, 19, 200, 100
     sd = orc.random_state_dict(U, k, L, T, seed=11)

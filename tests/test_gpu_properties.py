@@ -179,3 +179,46 @@ def test_c2_full_size_against_fp64_oracle():
     for key, v in nb.items():
         if "tracked" not in key:
             assert np.abs(bufs[key].cpu().numpy() - v).max() < 1e-4, key
+
+
+def test_c3_batch_and_tasks_against_fp64_oracle():
+    """Config C3's batch and task count (B = 4096, T = 50) at 32 units: the many-task head (MFMA
+    GEMMs for logits, d o and d Wf with K = 32 / 50 / 4096), the multi-block loss reduction
+    (B*T = 204 800 elements -> 25 blocks) and explainn_train_step's T > 4 branch, against the
+    numpy oracle in fp64.  Same tolerances as the C2 full-size test."""
+    from explainn_amd import ExplaiNN
+    from explainn_amd.engine import StepEngine
+    U3, T3, B3 = 32, 50, 4096
+    torch.manual_seed(21)
+    m = ExplaiNN(U3, K, L, T3).cuda().train()
+    m.dropout_p = 0.0
+    x = torch.from_numpy(orc.random_onehot(B3, L, seed=22, n_frac=0.002)).cuda()
+    y = (torch.rand(B3, T3, generator=torch.Generator().manual_seed(23)) > 0.5).float().cuda()
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    eng = StepEngine(m, B3, loss="binary")
+    logits, loss = eng.step(x, y)
+    torch.cuda.synchronize()
+    ref_logits, cache, _ = orc.forward(sd, x.cpu().numpy(), training=True, return_cache=True,
+                                       dtype=np.float64)
+    ref_loss, dl = orc.bce_with_logits(ref_logits, y.cpu().numpy().astype(np.float64))
+    ref = orc.backward(cache, dl)
+    assert np.abs(logits.cpu().numpy() - ref_logits).max() < 1e-4
+    assert abs(loss.item() - ref_loss) < 1e-5
+    for (name, _), g in zip(m.named_parameters(), eng.views):
+        r = ref[name].reshape(tuple(g.shape))
+        if name in ("linears.0.bias", "linears.6.bias", "linears.10.bias"):
+            assert g.abs().max().item() < 1e-6, name
+            continue
+        if name == "linears.1.bias":
+            continue
+        scale = np.abs(r).max()
+        tight = name.startswith(("final", "linears.11", "linears.10"))
+        err = np.abs(g.cpu().numpy() - r).max()
+        assert err <= (2e-4 if tight else 1e-2) * scale, (name, err, scale)
+    # the autograd path (torch's own BCE, explainn_backward) lands on the same gradients
+    m.zero_grad()
+    out = m(x)
+    torch.nn.functional.binary_cross_entropy_with_logits(out, y).backward()
+    assert torch.allclose(out, logits, atol=0, rtol=0)
+    for (name, p), g in zip(m.named_parameters(), eng.views):
+        assert torch.allclose(p.grad, g, rtol=1e-4, atol=1e-6 * float(g.abs().max()) + 1e-12), name
