@@ -1,6 +1,6 @@
 """Run a few train steps at the BASELINE.json secondary configurations (per-GPU shapes) and report
 time per step; parity at these shapes is covered by tests/ at small unit counts (same n)."""
-import sys, os, time
+import gc, sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from explainn_amd import ExplaiNN
@@ -17,6 +17,7 @@ for name, U, L, T, B in CONFIGS:
     idx = torch.randint(0, 4, (B, L))
     x = torch.zeros(B, 4, L).scatter_(1, idx[:, None, :], 1.0).to(dev)
     y = (torch.rand(B, T) > 0.5).float().to(dev)
+    gc.collect()            # a previous configuration's context is freed here, not inside the timed loop
     for _ in range(3): eng.step(x, y)
     torch.cuda.synchronize(); t0 = time.perf_counter(); K = 10
     for _ in range(K): eng.step(x, y)
