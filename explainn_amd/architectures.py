@@ -344,6 +344,8 @@ class ExplaiNN(_Model):
             return self._launch_train(x)[0]
         x = self._prep_input(x, dev)
         B = x.shape[0]
+        if B == 0:                                   # torch returns an empty (0, T) tensor in eval
+            return torch.empty(0, self._options["n_features"], device=dev, dtype=torch.float32)
         ctx = self._context(B, dev)
         ps, keep = self._params_struct(dev)
         logits = torch.empty(B, self._options["n_features"], device=dev, dtype=torch.float32)
@@ -357,6 +359,10 @@ class ExplaiNN(_Model):
         dev = self._device()
         x = self._prep_input(x, dev)
         B = x.shape[0]
+        if B == 0:
+            # what torch's BatchNorm1d raises for an empty batch in train mode
+            raise ValueError("Expected more than 1 value per channel when training, got input size "
+                             "[0, %d, 1]" % (FC_HIDDEN * self._options["cnn_units"]))
         ctx = self._context(B, dev)
         ps, keep = self._params_struct(dev)
         logits = torch.empty(B, self._options["n_features"], device=dev, dtype=torch.float32)

@@ -150,6 +150,15 @@ def test_edge_cases_small():
         m(torch.zeros(2, 4, 200))                          # host tensor, model on device
 
 
+def test_empty_batch_follows_torch():
+    from explainn_amd import ExplaiNN
+    m = ExplaiNN(4, 5, 40, 2).cuda()
+    x0 = torch.zeros(0, 4, 40).cuda()
+    assert tuple(m.eval()(x0).shape) == (0, 2)
+    with pytest.raises(ValueError):
+        m.train()(x0)
+
+
 def test_c2_full_size_against_fp64_oracle():
     """Train-mode logits and all gradients at the full C2 size against the numpy oracle in fp64
     (a few seconds of host time).  Logits within 1e-4; gradients upstream of the hidden ReLU within
