@@ -46,8 +46,12 @@ __global__ __launch_bounds__(64) void conv_pool_kernel(const uint32_t* __restric
     extern __shared__ __attribute__((aligned(16))) uint32_t csm[];
     float2* L2 = reinterpret_cast<float2*>(csm);            // [NT][16]
     float2* Wp = L2 + NT * 16;                              // [K][5]   per-tap table (N path)
-    uint32_t* pks = reinterpret_cast<uint32_t*>(Wp + K * 5); // [PW][64]
-    uint32_t* nms = pks + (size_t)PW * 64;                   // [NW][64]
+    // the packed codes are staged per chunk of CPW pooling windows: ~7 KB of LDS per wave at any
+    // sequence length (the whole of a 1000-bp sequence was 26 KB and cost two thirds of the occupancy)
+    constexpr int CPW = 32;
+    constexpr int PWC = ((POOLW * CPW + K + 15) >> 4) + 3, NWC = ((POOLW * CPW + K + 31) >> 5) + 2;
+    uint32_t* pks = reinterpret_cast<uint32_t*>(Wp + K * 5); // [PWC][64]
+    uint32_t* nms = pks + (size_t)PWC * 64;                  // [NWC][64]
     const int pair = blockIdx.y, lane = threadIdx.x;
     const int b = (blockIdx.x / wsplit) * 64 + lane;
     // the pooling windows of a (tile, pair) are split over `wsplit` wavefronts: more waves per
@@ -63,8 +67,6 @@ __global__ __launch_bounds__(64) void conv_pool_kernel(const uint32_t* __restric
             const float* w = Wt + ((size_t)quad * K + i / 5) * 20 + (i % 5) * 4 + off;
             Wp[i] = make_float2(w[0], w[1]);
         }
-        stage_column(pks + lane, pk2 + b, PW, Bs);
-        stage_column(nms + lane, nmask + b, NW, Bs);
     }
     // sign(alpha) = sign(gamma1): the pooling direction does not need the BatchNorm statistics,
     // so this kernel can run beside the input-moment chain
@@ -76,18 +78,24 @@ __global__ __launch_bounds__(64) void conv_pool_kernel(const uint32_t* __restric
     const char* Wb = reinterpret_cast<const char*>(Wp);
     const uint32_t* pl = pks + lane;
     const uint32_t* nl = nms + lane;
-    // window words of the first pooling window (the next one is prefetched inside the loop)
-    const int wi0 = (POOLW * wbeg) >> 4, ni0 = (POOLW * wbeg) >> 5;
+    for (int wc = wbeg; wc < wend; wc += CPW) {
+    // chunk origin in words; columns are lane-private, so no barrier is needed between chunks
+    const int w_lo = (POOLW * wc) >> 4, n_lo = (POOLW * wc) >> 5;
+    stage_column(pks + lane, pk2 + (size_t)w_lo * Bs + b, min(PWC, PW - w_lo), Bs);
+    stage_column(nms + lane, nmask + (size_t)n_lo * Bs + b, min(NWC, NW - n_lo), Bs);
+    // window words of the chunk's first pooling window (the next one is prefetched inside the loop)
+    const int wi0 = ((POOLW * wc) >> 4) - w_lo, ni0 = ((POOLW * wc) >> 5) - n_lo;
     uint32_t c0 = pl[wi0 * 64], c1 = pl[(wi0 + 1) * 64], c2 = pl[(wi0 + 2) * 64], c3 = pl[(wi0 + 3) * 64];
     uint32_t m0 = nl[ni0 * 64], m1 = nl[(ni0 + 1) * 64], m2 = nl[(ni0 + 2) * 64];
-    for (int w = wbeg; w < wend; ++w) {
+    const int wcend = min(wend, wc + CPW);
+    for (int w = wc; w < wcend; ++w) {
         const int p0 = POOLW * w;
         const int sh = (p0 & 15) * 2, nsh = p0 & 31;
         const uint32_t w0 = __funnelshift_r(c0, c1, sh), w1 = __funnelshift_r(c1, c2, sh),
                        w2 = __funnelshift_r(c2, c3, sh);
         const uint32_t nm0 = __funnelshift_r(m0, m1, nsh), nm1 = __funnelshift_r(m1, m2, nsh);
-        {   // prefetch the next window's words (rows past the sequence end are zero padding)
-            const int q0 = p0 + POOLW, wi = q0 >> 4, ni = q0 >> 5;
+        {   // prefetch the next window's words (past the chunk they are unused: the chunk restages)
+            const int q0 = p0 + POOLW, wi = (q0 >> 4) - w_lo, ni = (q0 >> 5) - n_lo;
             c0 = pl[wi * 64]; c1 = pl[(wi + 1) * 64]; c2 = pl[(wi + 2) * 64]; c3 = pl[(wi + 3) * 64];
             m0 = nl[ni * 64]; m1 = nl[(ni + 1) * 64]; m2 = nl[(ni + 2) * 64];
         }
@@ -140,6 +148,7 @@ __global__ __launch_bounds__(64) void conv_pool_kernel(const uint32_t* __restric
         ext[o0] = sg0 * best0; idx[o0] = (uint8_t)bi0;
         ext[o1] = sg1 * best1; idx[o1] = (uint8_t)bi1;
     }
+    }
     STAMP(2);
 }
 
@@ -162,7 +171,9 @@ __global__ __launch_bounds__(64) void conv_pool_kernel(const uint32_t* __restric
 
 static size_t conv_pool_lds(const explainn_ctx* c) {
     const int NT = (c->k + 1) / 2;
-    return (size_t)(NT * 16 + c->k * 5) * sizeof(float2) + (size_t)(c->PW + c->NW) * 64 * 4;
+    // tables + the chunk tiles [PWC + NWC][64] (see the kernel)
+    const int pwc = ((POOLW * 32 + c->k + 15) >> 4) + 3, nwc = ((POOLW * 32 + c->k + 31) >> 5) + 2;
+    return (size_t)(NT * 16 + c->k * 5) * sizeof(float2) + (size_t)(pwc + nwc) * 64 * 4;
 }
 
 int launch_conv_pool(explainn_ctx* c, const explainn_params* p, int B, hipStream_t s) {
