@@ -284,7 +284,13 @@ extern "C" int explainn_forward_train(explainn_ctx* c, const float* x, int B,
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     c->fwd_B = 0;
-    TRY(launch_pack(c, x, B, false, s));
+    // the one-hot batch is packed and the filter tables are built by one launch; a staged batch of
+    // base codes (x == NULL) is already packed and only needs the tables
+    if (x) TRY(launch_pack_tables(c, x, p, B, s));
+    else {
+        TRY(launch_pack(c, x, B, false, s));
+        TRY(launch_prep1_tables(c, p, s));
+    }
     // fork: the input-moment chain (pair counts -> Gram -> BatchNorm1 fold) needs only the packed
     // codes, the filter bank only the filter tables and sign(gamma1): run them side by side
     HIP_TRY(hipEventRecord(c->ev_fork, s));
@@ -292,7 +298,6 @@ extern "C" int explainn_forward_train(explainn_ctx* c, const float* x, int B,
     TRY(launch_moments(c, B, c->side));
     TRY(launch_prep1(c, p, B, true, c->side));
     HIP_TRY(hipEventRecord(c->ev_join, c->side));
-    TRY(launch_prep1_tables(c, p, s));
     TRY(launch_conv_pool(c, p, B, s));
     HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
     TRY(launch_qmoments(c, B, s));

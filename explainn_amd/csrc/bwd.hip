@@ -311,6 +311,53 @@ int launch_mid_bwd(explainn_ctx* c, const explainn_params* p, const explainn_gra
 }
 
 // ---------------------------------------------------------------------------------------------
+// BatchNorm1 backward closed form for one unit, by `nthr` threads of
+// one block: sums the per-tile partials in fixed order -> dW, d gamma1, d beta1.
+struct fin_args {
+    const float* S12p; const double* m; const double* Gw; const double* mug; const double* sig1;
+    const float* g1; float* g_conv_w; float* g_conv_b; float* g_bn1_w; float* g_bn1_b;
+    int K4; int freeze_n;
+};
+
+__device__ __forceinline__ void fin_unit(const fin_args& f, const float* __restrict__ Dspp, int u,
+                                         int tid, int nthr, int Bs, int B) {
+    const int K4 = f.K4;
+    const int NT = Bs / 64, nt = (B + 63) / 64;
+    const int NT32 = Bs / 32, nt32 = (B + 31) / 32;
+    double S1 = 0, S2 = 0;
+    for (int t0 = 0; t0 < nt32; t0 += 8) {
+        float2 pv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            pv[q] = *reinterpret_cast<const float2*>(&f.S12p[((size_t)u * NT32 + min(t0 + q, nt32 - 1)) * 2]);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { KEEP(pv[q].x); KEEP(pv[q].y); }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (t0 + q < nt32) { S1 += (double)pv[q].x; S2 += (double)pv[q].y; }
+    }
+    const double sg = f.sig1[u], a = (double)f.g1[u] / sg, mu = f.mug[u];
+    for (int i = tid; i < K4; i += nthr) {
+        double D = 0;
+        for (int t0 = 0; t0 < nt; t0 += 8) {           // eight partials in flight, fixed-order sum
+            float pv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) pv[q] = Dspp[((size_t)u * NT + min(t0 + q, nt - 1)) * K4 + i];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) KEEP(pv[q]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) D += (t0 + q < nt) ? (double)pv[q] : 0.0;
+        }
+        const double val = a * (D - S1 * f.m[i] - (S2 / sg) * (f.Gw[(size_t)u * K4 + i] - mu * f.m[i]));
+        f.g_conv_w[(size_t)u * K4 + i] = (u < f.freeze_n) ? 0.f : (float)val;
+    }
+    if (tid == 0) {
+        f.g_bn1_b[u] = (float)S1;
+        f.g_bn1_w[u] = (float)S2;
+        f.g_conv_b[u] = 0.f;
+    }
+}
+
 template <int K>
 __global__ __launch_bounds__(64, 5) void conv_bwd_kernel(const float* __restrict__ dy,
                                                          const uint8_t* __restrict__ idx,
@@ -464,53 +511,18 @@ int launch_conv_bwd(explainn_ctx* c, int B, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void fin_bwd_kernel(
-    const float* __restrict__ S12p, const float* __restrict__ Dspp, const double* __restrict__ m,
-    const double* __restrict__ Gw, const double* __restrict__ mug, const double* __restrict__ sig1,
-    const float* __restrict__ g1, float* __restrict__ g_conv_w, float* __restrict__ g_conv_b,
-    float* __restrict__ g_bn1_w, float* __restrict__ g_bn1_b, int K4, int Bs, int B, int freeze_n) {
-    const int u = blockIdx.x, tid = threadIdx.x;
-    const int NT = Bs / 64, nt = (B + 63) / 64;
-    const int NT32 = Bs / 32, nt32 = (B + 31) / 32;
-    double S1 = 0, S2 = 0;
-    for (int t0 = 0; t0 < nt32; t0 += 8) {
-        float2 pv[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            pv[q] = *reinterpret_cast<const float2*>(&S12p[((size_t)u * NT32 + min(t0 + q, nt32 - 1)) * 2]);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { KEEP(pv[q].x); KEEP(pv[q].y); }
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            if (t0 + q < nt32) { S1 += (double)pv[q].x; S2 += (double)pv[q].y; }
-    }
-    const double sg = sig1[u], a = (double)g1[u] / sg, mu = mug[u];
-    for (int i = tid; i < K4; i += 128) {
-        double D = 0;
-        for (int t0 = 0; t0 < nt; t0 += 8) {           // eight partials in flight, fixed-order sum
-            float pv[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) pv[q] = Dspp[((size_t)u * NT + min(t0 + q, nt - 1)) * K4 + i];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) KEEP(pv[q]);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) D += (t0 + q < nt) ? (double)pv[q] : 0.0;
-        }
-        const double val = a * (D - S1 * m[i] - (S2 / sg) * (Gw[(size_t)u * K4 + i] - mu * m[i]));
-        g_conv_w[(size_t)u * K4 + i] = (u < freeze_n) ? 0.f : (float)val;
-    }
-    if (tid == 0) {
-        g_bn1_b[u] = (float)S1;
-        g_bn1_w[u] = (float)S2;
-        g_conv_b[u] = 0.f;
-    }
+// One block per unit.  (Folding this into conv_bwd's last-arriving tile was tried: the device-scope
+// release every tile then needs -- an L2 write-back on this multi-XCD part -- cost 130 us per step.)
+__global__ __launch_bounds__(128) void fin_bwd_kernel(const fin_args fin,
+                                                      const float* __restrict__ Dspp, int Bs, int B) {
+    fin_unit(fin, Dspp, blockIdx.x, threadIdx.x, 128, Bs, B);
 }
 
 int launch_fin_bwd(explainn_ctx* c, const explainn_params* p, const explainn_grads* g, int B,
                    int freeze_n, hipStream_t s) {
-    hipLaunchKernelGGL(fin_bwd_kernel, dim3(c->U), dim3(128), 0, s, c->S12p, c->Dspp, c->m, c->Gw,
-                       c->mug, c->sig1, p->bn1_w, g->conv_w, g->conv_b, g->bn1_w, g->bn1_b, c->K4,
-                       c->Bs, B, freeze_n);
+    const fin_args fin = {c->S12p, c->m, c->Gw, c->mug, c->sig1, p->bn1_w, g->conv_w, g->conv_b,
+                          g->bn1_w, g->bn1_b, c->K4, freeze_n};
+    hipLaunchKernelGGL(fin_bwd_kernel, dim3(c->U), dim3(128), 0, s, fin, c->Dspp, c->Bs, B);
     LAUNCH_CHECK();
     return EXPLAINN_OK;
 }

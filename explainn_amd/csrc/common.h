@@ -105,6 +105,7 @@ int launch_prep1(explainn_ctx* c, const explainn_params* p, int B, bool train, h
 int launch_moments(explainn_ctx* c, int B, hipStream_t s);
 int launch_prep1_tables(explainn_ctx* c, const explainn_params* p, hipStream_t s);
 int launch_conv_pool(explainn_ctx* c, const explainn_params* p, int B, hipStream_t s);
+int launch_pack_tables(explainn_ctx* c, const float* x, const explainn_params* p, int B, hipStream_t s);
 int launch_pack_codes(explainn_ctx* c, const uint8_t* codes, int B, int rc, hipStream_t s);
 int launch_conv_act(explainn_ctx* c, int B, float* acts, hipStream_t s);
 int launch_filter_act_max(explainn_ctx* c, int B, const uint8_t* select, float* umax, hipStream_t s);
@@ -171,6 +172,35 @@ __device__ __forceinline__ void stage_column(uint32_t* __restrict__ tile_lane,
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             if (w0 + i < rows) tile_lane[(w0 + i) * 64] = t[i];
+    }
+}
+
+// The filter bank's lookup tables for unit u (all threads of the block call it): Wt (per-tap table,
+// unit-quad interleaved, entry 4 = N = zero) and lut (dinucleotide sums, unit-pair interleaved)
+// from the current filters.  wsh: 4*MAX_K floats of LDS.
+__device__ __forceinline__ void filter_tables_unit(const float* __restrict__ conv_w,
+                                                   float* __restrict__ Wt, float* __restrict__ lut,
+                                                   int U, int k, int u, int tid, int nthreads,
+                                                   float* wsh) {
+    const int K4 = 4 * k;
+    for (int i = tid; i < K4; i += nthreads) {
+        const int a = i / k, j = i % k;
+        const float wv = (u < U) ? conv_w[(size_t)u * K4 + i] : 0.f;
+        Wt[((size_t)(u >> 2) * k + j) * 20 + a * 4 + (u & 3)] = wv;
+        wsh[i] = wv;
+    }
+    for (int j = tid; j < k; j += nthreads) Wt[((size_t)(u >> 2) * k + j) * 20 + 16 + (u & 3)] = 0.f;
+    __syncthreads();
+    // lut[pair][t][c0 c1].{x,y} = W[u][c0][2t] + W[u][c1][2t+1]
+    const int NT = (k + 1) / 2;
+    for (int e = tid; e < NT * 16; e += nthreads) {
+        const int t = e >> 4, code4 = e & 15;
+        float sum = 0.f;
+        for (int i = 0; i < 2; ++i) {
+            const int j = 2 * t + i;
+            if (j < k) sum += wsh[((code4 >> (2 * i)) & 3) * k + j];
+        }
+        lut[(((size_t)(u >> 1) * NT + t) * 16 + code4) * 2 + (u & 1)] = sum;
     }
 }
 

@@ -15,16 +15,13 @@
 // in HBM at all -- optionally reverse-complemented on the fly (code' [p] = 3 - code[L-1-p], N stays
 // N: sequence/__init__.py:59-61 flips both axes of the one-hot).
 template <bool CODES>
-__global__ __launch_bounds__(256) void pack_onehot_kernel(const float* __restrict__ x,
-                                                          const uint8_t* __restrict__ codes_in,
-                                                          int rc,
-                                                          uint8_t* __restrict__ codesT,
-                                                          uint32_t* __restrict__ pk2,
-                                                          uint32_t* __restrict__ nmask, int B,
-                                                          int L, int Bs, int PW, int NW,
-                                                          int* __restrict__ flags) {
+__device__ __forceinline__ void pack_tile(const float* __restrict__ x,
+                                          const uint8_t* __restrict__ codes_in, int rc,
+                                          uint8_t* __restrict__ codesT, uint32_t* __restrict__ pk2,
+                                          uint32_t* __restrict__ nmask, int B, int L, int Bs, int PW,
+                                          int NW, int* __restrict__ flags, int bx, int by) {
     __shared__ uint8_t tile[64][68];
-    const int b0 = blockIdx.x * 64, p0 = blockIdx.y * 64;
+    const int b0 = bx * 64, p0 = by * 64;
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     int bad = 0;
     const int p = p0 + lane;
@@ -102,6 +99,38 @@ __global__ __launch_bounds__(256) void pack_onehot_kernel(const float* __restric
         }
     }
     if (bad) atomicOr(flags, 1);
+}
+
+template <bool CODES>
+__global__ __launch_bounds__(256) void pack_onehot_kernel(const float* __restrict__ x,
+                                                          const uint8_t* __restrict__ codes_in,
+                                                          int rc,
+                                                          uint8_t* __restrict__ codesT,
+                                                          uint32_t* __restrict__ pk2,
+                                                          uint32_t* __restrict__ nmask, int B,
+                                                          int L, int Bs, int PW, int NW,
+                                                          int* __restrict__ flags) {
+    pack_tile<CODES>(x, codes_in, rc, codesT, pk2, nmask, B, L, Bs, PW, NW, flags, blockIdx.x, blockIdx.y);
+}
+
+// Train forward: the pack tiles and the per-unit filter tables (which depend only on the weights)
+// in ONE launch -- the first gx*gy blocks pack, the following U4 blocks build tables; every launch
+// saved is ~4.5 us of this latency-bound pipeline.
+__global__ __launch_bounds__(256) void pack_tables_kernel(const float* __restrict__ x,
+                                                          uint8_t* __restrict__ codesT,
+                                                          uint32_t* __restrict__ pk2,
+                                                          uint32_t* __restrict__ nmask, int B,
+                                                          int L, int Bs, int PW, int NW,
+                                                          int* __restrict__ flags, int gx, int gy,
+                                                          const float* __restrict__ conv_w,
+                                                          float* __restrict__ Wt,
+                                                          float* __restrict__ lut, int U, int k) {
+    __shared__ float wsh[4 * MAX_K];
+    const int blk = blockIdx.x;                        // block-uniform role
+    if (blk < gx * gy)
+        pack_tile<false>(x, nullptr, 0, codesT, pk2, nmask, B, L, Bs, PW, NW, flags, blk % gx, blk / gx);
+    else
+        filter_tables_unit(conv_w, Wt, lut, U, k, blk - gx * gy, threadIdx.x, 256, wsh);
 }
 
 // one wavefront per (gap d, position q); lanes stride over the batch, the 16 pair bins are
@@ -188,6 +217,17 @@ int launch_pack(explainn_ctx* c, const float* x, int B, bool counts, hipStream_t
         LAUNCH_CHECK();
     }
     if (counts) return launch_moments(c, B, s);
+    return EXPLAINN_OK;
+}
+
+int launch_pack_tables(explainn_ctx* c, const float* x, const explainn_params* p, int B,
+                       hipStream_t s) {
+    const int gx = (B + 63) / 64, gy = (c->NW * 32 + 63) / 64;
+    c->staged_B = 0;
+    hipLaunchKernelGGL(pack_tables_kernel, dim3(gx * gy + c->U4), dim3(256), 0, s, x, c->codesT,
+                       c->pk2, c->nmask, B, c->L, c->Bs, c->PW, c->NW, c->flags, gx, gy, p->conv_w,
+                       c->Wt, c->lut, c->U, c->k);
+    LAUNCH_CHECK();
     return EXPLAINN_OK;
 }
 

@@ -27,26 +27,7 @@ __global__ __launch_bounds__(128) void prep1_tables_kernel(const float* __restri
                                                            float* __restrict__ Wt,
                                                            float* __restrict__ lut, int U, int k) {
     __shared__ float wsh[4 * MAX_K];
-    const int u = blockIdx.x, tid = threadIdx.x, K4 = 4 * k;
-    for (int i = tid; i < K4; i += 128) {
-        const int a = i / k, j = i % k;
-        const float wv = (u < U) ? conv_w[(size_t)u * K4 + i] : 0.f;
-        Wt[((size_t)(u >> 2) * k + j) * 20 + a * 4 + (u & 3)] = wv;
-        wsh[i] = wv;
-    }
-    for (int j = tid; j < k; j += 128) Wt[((size_t)(u >> 2) * k + j) * 20 + 16 + (u & 3)] = 0.f;
-    __syncthreads();
-    // lut[pair][t][c0 c1].{x,y} = W[u][c0][2t] + W[u][c1][2t+1]
-    const int NT = (k + 1) / 2;
-    for (int e = tid; e < NT * 16; e += 128) {
-        const int t = e >> 4, code4 = e & 15;
-        float sum = 0.f;
-        for (int i = 0; i < 2; ++i) {
-            const int j = 2 * t + i;
-            if (j < k) sum += wsh[((code4 >> (2 * i)) & 3) * k + j];
-        }
-        lut[(((size_t)(u >> 1) * NT + t) * 16 + code4) * 2 + (u & 1)] = sum;
-    }
+    filter_tables_unit(conv_w, Wt, lut, U, k, blockIdx.x, threadIdx.x, 128, wsh);
 }
 
 template <bool TRAIN>
