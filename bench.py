@@ -45,10 +45,12 @@ def measured_traffic():
         return None
 
 
-def synthetic_batch(B, seed, device):
+def synthetic_batch(B, seed, device, n_frac=0.0):
     g = torch.Generator().manual_seed(seed)
     idx = torch.randint(0, 4, (B, L), generator=g)
     x = torch.zeros(B, 4, L).scatter_(1, idx[:, None, :], 1.0)
+    if n_frac > 0:                                    # N bases = all-zero columns
+        x = x * (torch.rand(B, 1, L, generator=g) >= n_frac)
     y = (torch.rand(B, T, generator=torch.Generator().manual_seed(seed + 1)) > 0.5).float()
     return x.to(device), y.to(device)
 
@@ -91,6 +93,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--n-frac", type=float, default=0.0,
+                    help="fraction of N bases in the synthetic batch (robustness variant; the "
+                         "headline is 0)")
     ap.add_argument("--skip-optimizer", action="store_true",
                     help="skip the secondary fwd+bwd+Adam timing (profiling runs: one leg only)")
     args = ap.parse_args()
@@ -133,7 +138,7 @@ def main():
     # one-rank rehearsal its second collective cost more than the overlap saved
     overlap = os.environ.get("EXPLAINN_BENCH_OVERLAP", "0") == "1"
     P = eng.flat_grad.numel()
-    x, y = synthetic_batch(B_PER_GPU, 1000 + rank, dev)
+    x, y = synthetic_batch(B_PER_GPU, 1000 + rank, dev, args.n_frac)
 
     def one_step(i):
         if overlap:
@@ -224,6 +229,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
+        if args.n_frac > 0:
+            out["data"] = "synthetic, %.3g N bases" % args.n_frac
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

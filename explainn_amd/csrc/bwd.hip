@@ -364,11 +364,11 @@ __global__ __launch_bounds__(64, 5) void conv_bwd_kernel(const float* __restrict
                                                          const uint32_t* __restrict__ pk2,
                                                          const uint32_t* __restrict__ nmask,
                                                          float* __restrict__ Dspp, int U, int n,
-                                                         int Bs, int PW, int NW) {
+                                                         int Bs, int PW, int NW, int nlds_off) {
     // One wavefront = 64 sequences x one unit; lane = sequence.  The partial sums of a lane live in
     // REGISTERS: per tap three compare-select-adds for bases C,G,T; base A is recovered at the end
-    // as (sum of all dy) - C - G - T.  N positions are packed as 'C'; in the rare windows that
-    // contain one their dy is also summed wave-wide into scalar registers and taken out of C at the end.  No LDS traffic in the loop (LDS float atomics
+    // as (sum of all dy) - C - G - T.  N positions are packed as 'C'; the lanes that have one also add
+    // that dy to a per-tap LDS cell, which is taken out of C at the end.  No LDS traffic in the loop (LDS float atomics
     // serialise per lane on gfx950 and LDS read-modify-write chains were latency-bound,
     // profiles/r01_c); <= 102 VGPRs and 7 KB of LDS keep 5 waves per SIMD, i.e. the whole grid
     // resident in one round at C2.
@@ -386,9 +386,13 @@ __global__ __launch_bounds__(64, 5) void conv_bwd_kernel(const float* __restrict
     STAMP(0);
     constexpr uint32_t KMASK = (K >= 32) ? 0xffffffffu : ((1u << K) - 1u);
     float a1[K], a2[K], a3[K];
-    float nacc[K];                                     // wave-uniform (SGPRs)
 #pragma unroll
-    for (int j = 0; j < K; ++j) { a1[j] = 0.f; a2[j] = 0.f; a3[j] = 0.f; nacc[j] = 0.f; }
+    for (int j = 0; j < K; ++j) { a1[j] = 0.f; a2[j] = 0.f; a3[j] = 0.f; }
+    // dy that landed in the C bucket because an N base is packed as 'C', per tap: one LDS float per
+    // tap, fed by the few lanes that have an N (one wavefront per block, so the order of the adds
+    // -- lane order, instruction order -- is fixed and the sum reproducible)
+    float* nlds = reinterpret_cast<float*>(smem) + nlds_off;
+    if (lane < K) nlds[lane] = 0.f;
     float tot = 0.f;
     const float* __restrict__ dyu = dy + (size_t)u * n * Bs;
     const uint8_t* __restrict__ idxu = idx + (size_t)u * n * Bs;
@@ -433,14 +437,12 @@ __global__ __launch_bounds__(64, 5) void conv_bwd_kernel(const float* __restrict
                     a2[j] += (code == 2u) ? dyv : 0.f;
                     a3[j] += (code == 3u) ? dyv : 0.f;
                 }
-                if (__any(nm != 0u)) {
-                    // rare: some lane's window holds an N.  N is packed as 'C', so its dy went into
-                    // a1[j] and into tot: base A is already right (tot - a1 cancels it), and the C
-                    // bucket is corrected by the wave-wide sum of those dy, kept in scalar registers
-#pragma unroll
-                    for (int j = 0; j < K; ++j) {
-                        const float dn = wave_sum(((nm >> j) & 1u) ? dyv : 0.f);
-                        nacc[j] += __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, dn)));
+                uint32_t r = nm;
+                while (__any(r != 0u)) {
+                    if (r != 0u) {
+                        const int j = __ffs(r) - 1;
+                        r &= r - 1u;
+                        atomicAdd(&nlds[j], dyv);
                     }
                 }
                 tot += dyv;
@@ -465,12 +467,7 @@ __global__ __launch_bounds__(64, 5) void conv_bwd_kernel(const float* __restrict
             float sacc = 0.f;
 #pragma unroll 16
             for (int l = 0; l < 64; ++l) sacc += red[lane * 65 + l];
-            if (a == 1) {                              // lane j holds tap j: take its N sum out
-                float nj = 0.f;
-#pragma unroll
-                for (int j = 0; j < K; ++j) nj = (lane == j) ? nacc[j] : nj;
-                sacc -= nj;
-            }
+            if (a == 1) sacc -= nlds[lane];            // lane j holds tap j: take its N sum out
             out[a * K + lane] = sacc;
         }
     }
@@ -501,9 +498,11 @@ int launch_conv_bwd(explainn_ctx* c, int B, hipStream_t s) {
     size_t sm = (size_t)(pwc + nwc) * 64 * sizeof(uint32_t);
     const size_t red_bytes = (size_t)c->k * 65 * sizeof(float);
     if (sm < red_bytes) sm = red_bytes;
+    const int nlds_off = (int)(sm / sizeof(float));    // k floats behind the tiles: the N corrections
+    sm += (size_t)((c->k + 15) & ~15) * sizeof(float);
 #define CALL(KK)                                                                               \
     hipLaunchKernelGGL(conv_bwd_kernel<KK>, grid, dim3(64), sm, s, c->dy, c->idx, c->pk2, c->nmask, \
-                       c->Dspp, c->U, c->n, c->Bs, c->PW, c->NW)
+                       c->Dspp, c->U, c->n, c->Bs, c->PW, c->NW, nlds_off)
     KB_DISPATCH(c->k, CALL);
 #undef CALL
     LAUNCH_CHECK();

@@ -9,8 +9,8 @@
 // table read at random addresses would be ~3-4-way conflicted and give the gain back).
 // A lane owns one sequence and TWO units; the 2-mer index is 4 consecutive bits of the lane's
 // 2-bit packed sequence, taken from a 96-bit register window that slides 14 bits per pooling window.
-// Windows that contain an N (all-zero column) are rare; they take the per-tap table W[j][code]
-// (code 4 = zeros) instead, decided per wavefront and per window.
+// An N (all-zero column) is packed as 'C'; the lanes that have one in their window subtract the C
+// tap again (per-tap table W[j][code]), one N base at a time.
 // BatchNorm+exp are monotone per unit, so the 7-wide max-pool runs on the raw gather sums with the
 // sign of alpha = gamma1/sigma1 choosing max or min; only the pooled extreme (and its offset, for
 // the backward routing) leaves the kernel: ext[u][w][b], idx[u][w][b].
@@ -101,11 +101,10 @@ __global__ __launch_bounds__(64) void conv_pool_kernel(const uint32_t* __restric
         }
         constexpr uint32_t HIMASK = SPAN > 32 ? ((SPAN >= 64) ? 0xffffffffu : ((1u << (SPAN - 32)) - 1u)) : 0u;
         constexpr uint32_t LOMASK = SPAN >= 32 ? 0xffffffffu : ((1u << SPAN) - 1u);
-        const bool hasN = ((nm0 & LOMASK) | (nm1 & HIMASK)) != 0u;
         float2 acc[POOLW];
 #pragma unroll
         for (int i = 0; i < POOLW; ++i) acc[i] = make_float2(0.f, 0.f);
-        if (!__any(hasN)) {
+        {
             uint32_t a8[NX];
 #pragma unroll
             for (int x = 0; x < NX; ++x) a8[x] = dimer_off(w0, w1, w2, x);
@@ -117,22 +116,23 @@ __global__ __launch_bounds__(64) void conv_pool_kernel(const uint32_t* __restric
                     acc[i].x += v.x; acc[i].y += v.y;
                 }
             }
-        } else {
-            // per-tap path: code 4 (N) selects the zero entry
-            uint32_t co[SPAN];
-#pragma unroll
-            for (int x = 0; x < SPAN; ++x) {
-                const int bit = 2 * x;
-                const uint32_t c = (bit < 32 ? (w0 >> bit) : (bit < 64 ? (w1 >> (bit - 32)) : (w2 >> (bit - 64)))) & 3u;
-                const uint32_t isn = (x < 32 ? (nm0 >> x) : (nm1 >> (x - 32))) & 1u;
-                co[x] = (isn ? 4u : c) * 8u;
-            }
-#pragma unroll
-            for (int j = 0; j < K; ++j) {
+        }
+        // N bases are packed as 'C': take the C tap back out wherever the mask says N.  Per lane and
+        // per N base (a loop over the set bits; lanes without an N idle through it), instead of
+        // sending the whole wavefront down a 19-reads-per-position path because one lane saw an N.
+        uint32_t r0 = nm0 & LOMASK, r1 = nm1 & HIMASK;
+        while (__any((r0 | r1) != 0u)) {
+            if ((r0 | r1) != 0u) {
+                int x;
+                if (r0) { x = __ffs(r0) - 1; r0 &= r0 - 1u; }
+                else { x = 32 + __ffs(r1) - 1; r1 &= r1 - 1u; }
 #pragma unroll
                 for (int i = 0; i < POOLW; ++i) {
-                    const float2 v = *reinterpret_cast<const float2*>(Wb + j * 40 + co[i + j]);
-                    acc[i].x += v.x; acc[i].y += v.y;
+                    const int j = x - i;                 // base x of the window is tap j of position i
+                    if (j >= 0 && j < K) {
+                        const float2 v = *reinterpret_cast<const float2*>(Wb + j * 40 + 8);   // code 1 = C
+                        acc[i].x -= v.x; acc[i].y -= v.y;
+                    }
                 }
             }
         }
