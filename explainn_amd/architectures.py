@@ -268,13 +268,31 @@ class ExplaiNN(_Model):
         sd.update({k: v for k, v in self.named_buffers()})
         return sd
 
+    def __setattr__(self, name, value):
+        if name in ("final", "linears"):
+            self.__dict__.pop("_slots", None)          # sub-module replaced: re-resolve the slots
+        super().__setattr__(name, value)
+
+    def _param_slots(self):
+        """(C field, owning module, attribute) for the 23 tensors of explainn_params, resolved once:
+        the per-call lookup is then 23 getattr calls instead of walking named_parameters()."""
+        slots = self.__dict__.get("_slots")
+        if slots is None:
+            slots = []
+            for field in _lib.PARAM_FIELDS:
+                path = _lib.PARAM_KEYS[field].split(".")
+                mod = self
+                for part in path[:-1]:
+                    mod = mod[int(part)] if part.isdigit() else getattr(mod, part)
+                slots.append((field, mod, path[-1], torch.int64 if field.endswith("nbt") else torch.float32))
+            self.__dict__["_slots"] = slots
+        return slots
+
     def _params_struct(self, dev):
-        sd = self._tensors()
         ps = _lib.Params()
         keep = []
-        for field in _lib.PARAM_FIELDS:
-            t = sd[_lib.PARAM_KEYS[field]]
-            want = torch.int64 if field.endswith("nbt") else torch.float32
+        for field, mod, attr, want in self._param_slots():
+            t = getattr(mod, attr)          # looked up per call: callers may re-assign parameters
             if t.device != dev or t.dtype != want:
                 raise RuntimeError("parameter %s must be %s on %s (is %s on %s)" % (
                     _lib.PARAM_KEYS[field], want, dev, t.dtype, t.device))

@@ -364,7 +364,8 @@ __global__ __launch_bounds__(64, 5) void conv_bwd_kernel(const float* __restrict
                                                          const uint32_t* __restrict__ pk2,
                                                          const uint32_t* __restrict__ nmask,
                                                          float* __restrict__ Dspp, int U, int n,
-                                                         int Bs, int PW, int NW, int nlds_off) {
+                                                         int Bs, int PW, int NW, int nlds_off,
+                                                         int B) {
     // One wavefront = 64 sequences x one unit; lane = sequence.  The partial sums of a lane live in
     // REGISTERS: per tap three compare-select-adds for bases C,G,T; base A is recovered at the end
     // as (sum of all dy) - C - G - T.  N positions are packed as 'C'; the lanes that have one also add
@@ -417,7 +418,9 @@ __global__ __launch_bounds__(64, 5) void conv_bwd_kernel(const float* __restrict
             for (int q = 0; q < 2; ++q) { KEEP(dyq[q]); KEEP(psq[q]); }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                dyq[q] = (wb + q < wend) ? dyq[q] : 0.f;
+                // lanes past the batch (the last, partly filled tile) must not contribute: their dy
+                // is whatever an earlier, larger batch left there
+                dyq[q] = (wb + q < wend && b < B) ? dyq[q] : 0.f;
                 psq[q] += POOLW * min(wb + q, wend - 1);
             }
 #pragma unroll
@@ -502,7 +505,7 @@ int launch_conv_bwd(explainn_ctx* c, int B, hipStream_t s) {
     sm += (size_t)((c->k + 15) & ~15) * sizeof(float);
 #define CALL(KK)                                                                               \
     hipLaunchKernelGGL(conv_bwd_kernel<KK>, grid, dim3(64), sm, s, c->dy, c->idx, c->pk2, c->nmask, \
-                       c->Dspp, c->U, c->n, c->Bs, c->PW, c->NW, nlds_off)
+                       c->Dspp, c->U, c->n, c->Bs, c->PW, c->NW, nlds_off, B)
     KB_DISPATCH(c->k, CALL);
 #undef CALL
     LAUNCH_CHECK();

@@ -37,10 +37,10 @@ __device__ __forceinline__ void pack_tile(const float* __restrict__ x,
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = i0 + 4 * r, b = b0 + i;
-                uint8_t code = (p < L) ? 4 : 0;
+                uint8_t code = 0;                       // padding lanes / past the end: see below
                 if (b < B && p < L) {
                     if (v[r] < 4) code = rc ? 3 - v[r] : v[r];
-                    else if (v[r] != 4) bad = 1;        // not a base code: treated as N, flagged
+                    else { code = 4; if (v[r] != 4) bad = 1; }   // not a base code: N, flagged
                 }
                 tile[i][lane] = code;
             }
@@ -63,13 +63,15 @@ __device__ __forceinline__ void pack_tile(const float* __restrict__ x,
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = i0 + 4 * r, b = b0 + i;
-            uint8_t code = (p < L) ? 4 : 0;         // N for padding lanes, 'A' past the sequence end
+            // padding lanes (b >= B) and positions past the end are 'A': nothing reads their results,
+            // and as N they would drag their wavefront through the N corrections of the conv kernels
+            uint8_t code = 0;
             if (b < B && p < L) {
                 const float v0 = v[r][0], v1 = v[r][1], v2 = v[r][2], v3 = v[r][3];
                 const int ones = (v0 == 1.f) + (v1 == 1.f) + (v2 == 1.f) + (v3 == 1.f);
                 const int zeros = (v0 == 0.f) + (v1 == 0.f) + (v2 == 0.f) + (v3 == 0.f);
                 if (ones == 1 && zeros == 3) code = v0 == 1.f ? 0 : (v1 == 1.f ? 1 : (v2 == 1.f ? 2 : 3));
-                else if (zeros != 4) bad = 1;   // neither one-hot nor N: treated as N, flagged
+                else { code = 4; if (zeros != 4) bad = 1; }   // all-zero column = N; anything else: N, flagged
             }
             tile[i][lane] = code;
         }

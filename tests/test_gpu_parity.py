@@ -418,3 +418,34 @@ def test_split_step_equals_fused_step_and_overlapped_allreduce():
     rc = eng.ctx.lib.explainn_train_step_conv(eng.ctx.handle, g.B, ctypes.byref(eng.ps),
                                               ctypes.byref(eng.gs), 0, None)
     assert rc == _lib.E_STATE
+
+
+def test_smaller_batch_after_larger_one_on_the_same_context():
+    """A ragged batch (70) after a larger one (128) on the same context: the lanes of the last,
+    partly filled 64-sequence tile still hold the larger batch's intermediates and must not leak
+    into the gradients (the last epoch batch of every Trainer run looks like this)."""
+    from explainn_amd.engine import StepEngine
+    U, k, L, T = 6, 19, 200, 2
+    sd = orc.random_state_dict(U, k, L, T, seed=31)
+    m = _model(sd, U, k, L, T).train()
+    m.dropout_p = 0.0
+    eng = StepEngine(m, 128, loss="binary")
+    rng = np.random.default_rng(32)
+    xb = orc.random_onehot(128, L, seed=33, n_frac=0.01)
+    yb = (rng.random((128, T)) > 0.5).astype(np.float32)
+    eng.step(torch.from_numpy(xb).cuda(), torch.from_numpy(yb).cuda())
+    m.load_state_dict({key: torch.from_numpy(np.array(v)) for key, v in sd.items()})   # undo BN buffer updates
+    xs, ys = xb[:70] * 1.0, yb[:70]
+    xs = orc.random_onehot(70, L, seed=34, n_frac=0.01)
+    logits, loss = eng.step(torch.from_numpy(xs).cuda(), torch.from_numpy(ys).cuda())
+    torch.cuda.synchronize()
+    ref_logits, cache, _ = orc.forward(sd, xs, training=True, return_cache=True)
+    ref_loss, dl = orc.bce_with_logits(ref_logits, ys)
+    ref_grads = orc.backward(cache, dl)
+    _close(_np(logits), ref_logits, what="logits")
+    _close(loss.item(), ref_loss, tol=1e-5, what="loss")
+    for (key, _), v in zip(m.named_parameters(), eng.views):
+        if key in ZERO_GRAD:
+            assert np.abs(_np(v)).max() < 1e-6, key
+        else:
+            _close(_np(v).reshape(ref_grads[key].shape), ref_grads[key], tol=2e-4, what="grad " + key)

@@ -89,7 +89,7 @@ int main() {
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
             if (rep) report("conv_pool", 16 * 2 * (U4 / 2), 3, ms);
             CK(hipEventRecord(e0));
-            hipLaunchKernelGGL(conv_bwd_kernel<19>, dim3(16, U), dim3(64), (size_t)(PW + NW) * 256 + 128, 0, dy, idx, pk2, nmask, Dspp, U, n, Bs, PW, NW, (PW + NW) * 64);
+            hipLaunchKernelGGL(conv_bwd_kernel<19>, dim3(16, U), dim3(64), (size_t)(PW + NW) * 256 + 128, 0, dy, idx, pk2, nmask, Dspp, U, n, Bs, PW, NW, (PW + NW) * 64, B);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
             if (rep) report("conv_bwd", 16 * U, 4, ms);
             CK(hipEventRecord(e0));
