@@ -151,3 +151,40 @@ def test_pwm_scan_wide_bank_vs_oracle():
         got = PWM(pwms, 200, scoring).cuda()(torch.from_numpy(x).cuda()).cpu().numpy()
         ref = eo.pwm_scan(pwms, x, scoring)
         assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_interpret_entry_point_writes_reference_layout(tmp_path):
+    """explainn_amd.interpret.main on a saved checkpoint + TSV: the files interpret.py:128-235 leaves
+    behind (output-layer weights, filter importances, one JASPAR motif per filter), with the counts
+    the fixture holds."""
+    import gzip
+    from explainn_amd import interpret as it
+    from explainn_amd import sequence as sq
+    z, m = load("pfm_u8_k9")
+    net = _model(z, m)
+    seqs = sq.one_hot_decode_many(onehot(z["codes"]))
+    tsv = tmp_path / "train.tsv"
+    with open(tsv, "wt") as fh:
+        for i, (s, y) in enumerate(zip(seqs, z["labels"])):
+            fh.write("seq%d\t%s\t%s\n" % (i, s, "\t".join(str(int(v)) for v in y)))
+    ckpt = tmp_path / "best_model.pth.tar"
+    torch.save({"step": 1, "arch": "ExplaiNN", "options": dict(net._options),
+                "state_dict": {k: v.cpu() for k, v in net.state_dict().items()}, "min_loss": 0.0,
+                "optimizer": {}}, ckpt)
+    out = tmp_path / "out"
+    it.main([str(ckpt), str(tsv), "-n", "demo", "-o", str(out), "-b", "16", "-t"])
+    weights = np.loadtxt(out / "output-layer-weights.tsv", skiprows=1, usecols=1, ndmin=1)
+    assert np.allclose(weights, z["sd/final.weight"][0], atol=1e-6)
+    for u in range(m["U"]):
+        txt = open(out / "motifs" / ("filter%d.jaspar" % u)).read()
+        if z["nsites"][u] == 0:
+            assert txt == ""
+            continue
+        lines = txt.splitlines()
+        assert lines[0] == ">filter%d demo" % u
+        counts = np.array([[float(v) for v in ln[ln.index("[") + 1:ln.index("]")].split()] for ln in lines[1:]])
+        assert np.array_equal(counts.T, z["pfm"][u])
+    with gzip.open(out / "filter-importances.tsv.gz", "rt") as fh:
+        rows = fh.read().splitlines()
+    assert len(rows) - 1 == sum(len(z["imp_sel/%d" % u]) for u in range(m["U"]))
+    assert (out / "time-interpret.py.txt").exists()
