@@ -45,6 +45,26 @@ def measured_traffic():
         return None
 
 
+def measured_copy_peak(device):
+    """Device-to-device copy rate on this box (read + write bytes / time), the practical HBM roof
+    next to the 8 TB/s spec (SURVEY.md 8d asks for both)."""
+    n = 1 << 28                                        # 1 GiB of fp32 per buffer, beyond the 256 MB cache
+    a = torch.empty(n, device=device, dtype=torch.float32).fill_(1.0)
+    b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    gbps = 5 * 2 * n * 4 / (e0.elapsed_time(e1) / 1e3) / 1e9
+    del a, b
+    torch.cuda.empty_cache()
+    return round(gbps, 1)
+
+
 def synthetic_batch(B, seed, device, n_frac=0.0):
     g = torch.Generator().manual_seed(seed)
     idx = torch.randint(0, 4, (B, L), generator=g)
@@ -196,6 +216,7 @@ def main():
         alg = algorithmic_bytes_per_step(B_PER_GPU, P)
         achieved = alg / step_gpu_s / 1e9
         traffic = measured_traffic() if world == 1 else None
+        copy_peak = measured_copy_peak(dev) if world == 1 else None
         out = {
             "metric": "sequences/sec (fwd+bwd), 200bp one-hot, 300 units, batch 1024",
             "value": round(seqs / wall, 1), "unit": "sequences/s", "n_gpus": world,
@@ -217,6 +238,7 @@ def main():
                          "measured_frac": round(traffic / step_gpu_s / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None,
                          "traffic_note": "bytes per step, FETCH_SIZE(x2)+WRITE_SIZE from profiles/"
                                          "r01_final_traffic.json (separate rocprofv3 --pmc passes)",
+                         "copy_peak_GBps_measured_here": copy_peak,
                          "kernel": "train_step pipeline (all launches of one step)",
                          "algorithmic_bytes_per_step": alg,
                          "gpu_ms_per_step_hip_events": round(step_gpu_s * 1e3, 4)},
