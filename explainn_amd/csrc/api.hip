@@ -137,7 +137,7 @@ extern "C" int explainn_create(explainn_ctx** out, int cnn_units, int kernel_siz
     c->U = cnn_units; c->k = kernel_size; c->L = sequence_length; c->T = n_features;
     c->maxB = max_batch; c->device = device;
     c->Lo = Lo; c->n = n; c->U4 = (cnn_units + 3) & ~3; c->Uq = c->U4 / 4;
-    c->NQ = NQ; c->NS = ns_stride(NQ); c->NX = fcx_stride(NQ); c->K4 = 4 * kernel_size;
+    c->NQ = NQ; c->NS = ns_stride(NQ); c->K4 = 4 * kernel_size;
     // Batch stride of every [..][b] array: a multiple of 64 lanes, but an ODD multiple, so that the
     // row stride (4*Bs bytes) is never a multiple of 512 B: with Bs = 1024 every row of ext/dy/...
     // was exactly 4096 B apart and all rows of a wavefront (and of every unit) landed on the same

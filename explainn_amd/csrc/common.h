@@ -57,7 +57,6 @@ struct explainn_ctx {
     float* VC;            // [U][100][NS]     V1 . C  (BN2 variance in prep2, BN2 backward in mid)
     float* A2;            // [U][100][NS]     FC1 weights with BN2 folded in
     float* A2f;           // [U][4][NKS][64]  the same in MFMA A-fragment order (fc_fwd stages it)
-    int NX;
     float* sh2;           // [U][100]
     float* sig2;          // [U][100]
     float* z;             // [U][Bs]          FC2 output (without its bias)
@@ -221,18 +220,15 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
-// Row geometry of the scalar-operand tables.  A row of NQ payload floats is cut into NCH chunks of
-// CH floats (CH a multiple of 4, at most 36 so that two chunk buffers fit the SGPR file).
+// Row stride NS of every per-unit table with one entry per pooled position (q, T, M, EQ, VC rows):
+// NQ rounded up in chunks of at most 36 floats, each a multiple of 4 (float4-aligned rows; the
+// chunking dates from the scalar-operand FC of profiles/r01_b and is kept as the layout).
 __host__ __device__ constexpr int chunk_count(int len) { return (len + 35) / 36; }
 __host__ __device__ constexpr int chunk_len(int len) {
     return (((len + chunk_count(len) - 1) / chunk_count(len)) + 3) & ~3;
 }
 // q / T / M / EQ rows: NQ payload floats
 __host__ __device__ constexpr int ns_stride(int NQ) { return chunk_count(NQ) * chunk_len(NQ); }
-__host__ __device__ constexpr int row_chunk(int NS) { return NS / chunk_count(NS); }
-// fc_fwd rows: [sh2, V2, A2[0..NQ)]
-__host__ __device__ constexpr int fcx_stride(int NQ) { return chunk_count(NQ + 2) * chunk_len(NQ + 2); }
-__host__ __device__ constexpr int fcx_chunk(int NQ) { return chunk_len(NQ + 2); }
 
 // pooled-length buckets with instantiated FC kernels (0 if unsupported)
 static inline int nq_bucket(int n) {
