@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <cstdlib>
+#include <cstring>
 
 #include "common.h"
 
@@ -77,6 +78,7 @@ void carve(explainn_ctx* c, Carver& cv) {
     cv.take(&c->Dspp, U * (Bs / 64) * K4);
     cv.take(&c->dlogits, (int64_t)c->maxB * c->T);
     cv.take(&c->flags, 64);
+    cv.take(&c->seed_dev, 64);
     cv.take(&c->dlT, (int64_t)c->T * Bs);
     cv.take(&c->lossp, 64);
     cv.take(&c->site_cnt, U4 * Bs);
@@ -184,6 +186,7 @@ extern "C" int explainn_create(explainn_ctx** out, int cnn_units, int kernel_siz
     HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->seed_ring), SEED_RING * 2 * sizeof(uint32_t), hipHostMallocDefault));
     int rc = prep_configure(c);
     if (rc == EXPLAINN_OK) rc = bwd_configure(c);
     if (rc == EXPLAINN_OK) rc = fc_configure(c);
@@ -198,6 +201,8 @@ extern "C" void explainn_destroy(explainn_ctx* c) {
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->graph_exec) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(c->graph_exec));
+    if (c->seed_ring) (void)hipHostFree(c->seed_ring);
     if (c->base) (void)hipFree(c->base);
     delete c;
 }
@@ -382,12 +387,105 @@ int train_step_front(explainn_ctx* c, const float* x, const float* targets, int 
 }
 }  // namespace
 
+namespace {
+// ---- hipGraph replay of the whole step ------------------------------------------------------------
+// The step is 15 launches on two streams, identical from call to call when the caller reuses its
+// buffers (bench.py, a training loop over device-resident data).  Once the same arguments have
+// been seen three times in a row the step is captured (stream capture, the forked side stream
+// included) and from then on replayed with ONE hipGraphLaunch; only the dropout seed changes and
+// travels through device memory.  Any other argument change falls back to direct launches and
+// re-arms the capture.
+// OFF by default (EXPLAINN_GRAPH=1 turns it on): measured on MI355X / ROCm 7.2 the replay is not
+// faster than the direct launches -- 0.353 vs 0.343 ms at C2, 0.166 vs 0.164 ms at the C1 shape
+// (tools/graph_probe.py); the runtime already issues the launches back to back and the graph adds
+// its own dependencies.  Kept, tested, for runtimes where that changes.
+struct step_key {
+    const void* x; const void* y; const void* logits; const void* loss;
+    explainn_params p; explainn_grads g;
+    int B, loss_kind, freeze; float dropout_p;
+};
+
+bool graphs_enabled() {
+    const char* e = getenv("EXPLAINN_GRAPH");          // read per call: tests toggle it
+    return e && e[0] == '1';
+}
+
+int step_direct(explainn_ctx* c, const float* x, const float* targets, int B, const explainn_params* p,
+                const explainn_grads* g, int loss_kind, float dropout_p, uint64_t seed, int freeze,
+                float* logits, float* loss_out, void* stream) {
+    TRY(train_step_front(c, x, targets, B, p, g, loss_kind, dropout_p, seed, logits, loss_out, stream));
+    return backward_conv(c, B, p, g, freeze, static_cast<hipStream_t>(stream));
+}
+
+int push_seed(explainn_ctx* c, uint64_t seed, hipStream_t s) {
+    uint32_t* slot = c->seed_ring + 2 * (c->seed_slot++ % SEED_RING);
+    slot[0] = (uint32_t)seed; slot[1] = (uint32_t)(seed >> 32);
+    HIP_TRY(hipMemcpyAsync(c->seed_dev, slot, 2 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    return EXPLAINN_OK;
+}
+}  // namespace
+
 extern "C" int explainn_train_step(explainn_ctx* c, const float* x, const float* targets, int B,
                                    const explainn_params* p, const explainn_grads* g, int loss_kind,
                                    float dropout_p, uint64_t seed, int freeze_top_n_filters,
                                    float* logits, float* loss_out, void* stream) {
-    TRY(train_step_front(c, x, targets, B, p, g, loss_kind, dropout_p, seed, logits, loss_out, stream));
-    return backward_conv(c, B, p, g, freeze_top_n_filters, static_cast<hipStream_t>(stream));
+    static_assert(sizeof(step_key) <= sizeof(c->graph_key), "graph key buffer too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // stream 0 (the legacy default stream) cannot be captured; staged base codes change per call
+    const bool eligible = graphs_enabled() && c && x && p && g && s != nullptr && B > 1;
+    if (!eligible)
+        return step_direct(c, x, targets, B, p, g, loss_kind, dropout_p, seed, freeze_top_n_filters,
+                           logits, loss_out, stream);
+    step_key key;
+    memset(&key, 0, sizeof(key));
+    key.x = x; key.y = targets; key.logits = logits; key.loss = loss_out; key.p = *p; key.g = *g;
+    key.B = B; key.loss_kind = loss_kind; key.freeze = freeze_top_n_filters; key.dropout_p = dropout_p;
+    if (c->graph_exec && memcmp(&key, c->graph_key, sizeof(key)) == 0) {
+        TRY(push_seed(c, seed, s));
+        HIP_TRY(hipGraphLaunch(static_cast<hipGraphExec_t>(c->graph_exec), s));
+        c->fwd_B = B; c->tail_B = 0; c->staged_B = 0;
+        return EXPLAINN_OK;
+    }
+    if (memcmp(&key, c->seen_key, sizeof(key)) == 0) ++c->seen_count;
+    else { memcpy(c->seen_key, &key, sizeof(key)); c->seen_count = 1; }
+    if (c->seen_count < 3)
+        return step_direct(c, x, targets, B, p, g, loss_kind, dropout_p, seed, freeze_top_n_filters,
+                           logits, loss_out, stream);
+    // capture (nothing executes), instantiate, then run this call through the graph as well
+    if (c->graph_exec) {
+        (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(c->graph_exec));
+        c->graph_exec = nullptr;
+    }
+    c->seen_count = 0;
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        return step_direct(c, x, targets, B, p, g, loss_kind, dropout_p, seed, freeze_top_n_filters,
+                           logits, loss_out, stream);
+    }
+    c->capturing = true;
+    const int rc = step_direct(c, x, targets, B, p, g, loss_kind, dropout_p, seed,
+                               freeze_top_n_filters, logits, loss_out, stream);
+    c->capturing = false;
+    const hipError_t ee = hipStreamEndCapture(s, &graph);
+    hipGraphExec_t exec = nullptr;
+    if (rc != EXPLAINN_OK || ee != hipSuccess || graph == nullptr ||
+        hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        if (graph) (void)hipGraphDestroy(graph);
+        // capture is not available here: run directly (and stop trying for this context)
+        c->seen_count = -(1 << 30);
+        return step_direct(c, x, targets, B, p, g, loss_kind, dropout_p, seed, freeze_top_n_filters,
+                           logits, loss_out, stream);
+    }
+    (void)hipGraphDestroy(graph);
+    c->graph_exec = exec;
+    memcpy(c->graph_key, &key, sizeof(key));
+    c->graph_key_len = (int)sizeof(key);
+    TRY(push_seed(c, seed, s));
+    HIP_TRY(hipGraphLaunch(exec, s));
+    c->fwd_B = B; c->tail_B = 0; c->staged_B = 0;
+    return EXPLAINN_OK;
 }
 
 extern "C" int explainn_train_step_fc(explainn_ctx* c, const float* x, const float* targets, int B,

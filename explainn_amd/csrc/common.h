@@ -8,6 +8,7 @@
 #include "../../include/explainn_hip.h"
 
 #define FC_H 100          // hidden width of the per-unit FC (architectures/__init__.py:86)
+#define SEED_RING 1024      // pinned host slots the per-step dropout seeds are copied from (graph replay)
 #define HEAD_GEMM_MIN_T 8   // more tasks than this: combiner forward/backward as MFMA GEMMs (head.hip)
 #define POOLW 7           // MaxPool1d(7,7)        (architectures/__init__.py:81)
 #define BN_EPS_D 1e-5     // architectures/__init__.py:79,90,99
@@ -79,6 +80,16 @@ struct explainn_ctx {
     float* dlogits;       // [maxB][T]         (train_step only)
     float* dlT;           // [T][Bs]   d loss / d logits, task-major (head GEMMs, T > HEAD_GEMM_MIN_T)
     double* lossp;        // [64]      per-block partial sums of the loss
+    // hipGraph replay of explainn_train_step (api.hip): the step is captured once its arguments
+    // have repeated, then replayed with one launch; the dropout seed travels through seed_dev
+    uint32_t* seed_dev;   // [2]   device copy of the current seed (read by fc_fwd when captured)
+    uint32_t* seed_ring;  // [SEED_RING][2] pinned host ring the seeds are copied from
+    unsigned seed_slot;
+    bool capturing;
+    void* graph_exec;     // hipGraphExec_t
+    unsigned char graph_key[512];
+    unsigned char seen_key[512];
+    int graph_key_len, seen_count;
     int staged_B;         // batch size of the codes explainn_stage_codes() staged, 0 = none
     int* flags;           // [1]
     int* site_cnt;        // [U4][Bs]  sites per (unit, sequence) of the current batch (filter->PWM export)

@@ -42,9 +42,12 @@ __global__ __launch_bounds__(256, (NQ <= 32 ? 5 : 1)) void fc_fwd_kernel(
     const uint8_t* __restrict__ keep_mask, uint32_t thresh16, float scale, uint32_t seed_lo,
     uint32_t seed_hi, const float* __restrict__ c2, const float* __restrict__ g3,
     const float* __restrict__ b3, const float* __restrict__ rm3, const float* __restrict__ rv3,
-    float* __restrict__ oout, int n, int Bs, int B, int U) {
+    float* __restrict__ oout, int n, int Bs, int B, int U, const uint32_t* __restrict__ seed_dev) {
     constexpr int NS = ns_stride(NQ), NKS = (NQ + 1) / 2;
     constexpr bool TRAIN = MODE != 0;
+    // a captured step (hipGraph) reads its dropout seed from device memory, so that replays can
+    // use a new one; direct launches pass it by value
+    if (MODE == 2 && seed_dev) { seed_lo = seed_dev[0]; seed_hi = seed_dev[1]; }
     __shared__ __attribute__((aligned(16))) float Af[FC_RT * NKS * 64];
     __shared__ __attribute__((aligned(16))) float sh2s[128];
     __shared__ __attribute__((aligned(16))) float v2s[128];
@@ -161,7 +164,8 @@ int launch_fc_fwd(explainn_ctx* c, const explainn_params* p, int B, bool train,
     if (train) { c->fwd_drop = mode > 1; c->fwd_scale = scale; }
 #define ARGS c->ext, c->alpha, c->shift, c->A2f, c->sh2, p->fc2_w, c->bits, c->z, keep_mask, thresh, \
              scale, (uint32_t)seed, (uint32_t)(seed >> 32), p->fc2_b, p->bn3_w, p->bn3_b,          \
-             p->bn3_rm, p->bn3_rv, c->o, c->n, c->Bs, B, c->U
+             p->bn3_rm, p->bn3_rv, c->o, c->n, c->Bs, B, c->U,                                   \
+             (c->capturing ? c->seed_dev : (const uint32_t*)nullptr)
 #define CALL(N)                                                                                    \
     switch (mode) {                                                                                \
         case 0: hipLaunchKernelGGL((fc_fwd_kernel<N, 0>), grid, dim3(256), 0, s, ARGS); break;     \

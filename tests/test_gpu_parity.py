@@ -449,3 +449,39 @@ def test_smaller_batch_after_larger_one_on_the_same_context():
             assert np.abs(_np(v)).max() < 1e-6, key
         else:
             _close(_np(v).reshape(ref_grads[key].shape), ref_grads[key], tol=2e-4, what="grad " + key)
+
+
+def test_graph_replay_equals_direct_launches():
+    """With EXPLAINN_GRAPH=1, on a non-default stream, explainn_train_step captures itself into a
+    hipGraph once its arguments have repeated three times and replays it afterwards (seed through
+    device memory).
+    Every step must equal, bit for bit, the same step issued as direct launches on the default
+    stream -- dropout on, so a stale seed would show -- and a changed argument must fall back."""
+    import os
+    from explainn_amd.engine import StepEngine
+    g = Golden("mid_u8_k19_L200")
+    x = torch.from_numpy(g.onehot()).cuda()
+    y = torch.from_numpy(g.targets().astype(np.float32)).cuda()
+    engines = []
+    os.environ["EXPLAINN_GRAPH"] = "1"                  # opt-in (off by default: no faster, DESIGN.md)
+    for _ in range(2):
+        m = _model(g.sd(), g.U, g.k, g.L, g.T).train()
+        m.dropout_p = 0.3
+        engines.append(StepEngine(m, g.B, loss=g.loss_kind))
+    direct, graphed = engines
+    side = torch.cuda.Stream()
+    x2 = x.clone()
+    for it in range(9):
+        xin = x2 if it == 6 else x                      # step 6: another input buffer -> direct fallback
+        a = direct.step(xin, y, seed=100 + it)
+        ref = (a[0].clone(), a[1].clone(), direct.flat_grad.clone())
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            b = graphed.step(xin, y, seed=100 + it)
+        side.synchronize()
+        assert torch.equal(ref[0], b[0]) and torch.equal(ref[1], b[1]), it
+        assert torch.equal(ref[2], graphed.flat_grad), it
+    os.environ.pop("EXPLAINN_GRAPH", None)
+    # BatchNorm buffers advanced identically (they are updated inside the captured kernels)
+    for (ka, va), (kb, vb) in zip(direct.model.state_dict().items(), graphed.model.state_dict().items()):
+        assert torch.equal(va, vb), ka
