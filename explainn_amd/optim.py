@@ -29,6 +29,38 @@ class FusedAdam(torch.optim.Adam):
                 return False
         return True
 
+    def _plan(self, gi, group, params):
+        """Everything about a parameter group that does not change from step to step -- the ctypes
+        pointer tables of parameters / gradients / moments, the sizes, the step tensors -- built
+        once and reused while the same tensor objects are in place (a training loop keeps them)."""
+        plan = self.__dict__.setdefault("_plans", {}).get(gi)
+        if plan is not None and len(plan["params"]) == len(params) and \
+                all(a is b for a, b in zip(plan["params"], params)) and \
+                all(p.grad is g for p, g in zip(params, plan["grads"])):
+            return plan
+        steps, ms, vs = [], [], []
+        for p in params:
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            elif st["step"].device.type != "cpu":
+                st["step"] = st["step"].cpu()
+            steps.append(st["step"]); ms.append(st["exp_avg"]); vs.append(st["exp_avg_sq"])
+        n = len(params)
+        grads = [p.grad for p in params]
+
+        def arr(ts):
+            return (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+
+        plan = {"params": list(params), "grads": grads, "steps": steps, "ms": ms, "vs": vs, "n": n,
+                "p_arr": arr(params), "g_arr": arr(grads), "m_arr": arr(ms), "v_arr": arr(vs),
+                "sizes": (C.c_int64 * n)(*[p.numel() for p in params]),
+                "uniform": len({float(t) for t in steps}) == 1}
+        self._plans[gi] = plan
+        return plan
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -37,38 +69,45 @@ class FusedAdam(torch.optim.Adam):
                 loss = closure()
         groups = [(g, [p for p in g["params"] if p.grad is not None]) for g in self.param_groups]
         if not all(self._fusable(g, ps) for g, ps in groups):
+            self.__dict__.pop("_plans", None)
             super().step()
             return loss
         lib = _lib.load()
-        for group, params in groups:
+        for gi, (group, params) in enumerate(groups):
             if not params:
                 continue
-            # one launch per distinct step count (all equal unless parameters were added later)
-            by_step = {}
-            for p in params:
-                st = self.state[p]
-                if len(st) == 0:
-                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                if st["step"].device.type != "cpu":
-                    st["step"] = st["step"].cpu()
-                st["step"] += 1
-                by_step.setdefault(int(st["step"].item()), []).append(p)
+            plan = self._plan(gi, group, params)
+            # state tensors can be swapped under us (load_state_dict): the plan must still match
+            st0 = self.state[params[0]]
+            if st0["exp_avg"] is not plan["ms"][0] or st0["step"] is not plan["steps"][0] or \
+                    any(not g.is_contiguous() for g in plan["grads"]):
+                self._plans.pop(gi, None)
+                plan = self._plan(gi, group, params)
+                if any(not g.is_contiguous() for g in plan["grads"]):
+                    self.__dict__.pop("_plans", None)
+                    super().step()
+                    return loss
+            torch._foreach_add_(plan["steps"], 1)
             beta1, beta2 = group["betas"]
-            for step, ps in by_step.items():
-                n = len(ps)
-                grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
-
-                def arr(ts):
-                    return (C.c_void_p * n)(*[t.data_ptr() for t in ts])
-
-                dev = ps[0].device
-                with torch.cuda.device(dev):
+            dev = params[0].device
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            with torch.cuda.device(dev):
+                if plan["uniform"]:
                     _lib.check(lib.explainn_adam_step(
-                        n, arr(ps), arr(grads), arr([self.state[p]["exp_avg"] for p in ps]),
-                        arr([self.state[p]["exp_avg_sq"] for p in ps]),
-                        (C.c_int64 * n)(*[p.numel() for p in ps]), step, float(group["lr"]),
-                        float(beta1), float(beta2), float(group["eps"]),
-                        C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+                        plan["n"], plan["p_arr"], plan["g_arr"], plan["m_arr"], plan["v_arr"],
+                        plan["sizes"], int(plan["steps"][0].item()), float(group["lr"]), float(beta1),
+                        float(beta2), float(group["eps"]), stream))
+                else:
+                    # parameters added later carry their own step count: one launch per tensor
+                    for i in range(plan["n"]):
+                        one = lambda a: (C.c_void_p * 1)(a[i])   # noqa: E731
+                        _lib.check(lib.explainn_adam_step(
+                            1, one(plan["p_arr"]), one(plan["g_arr"]), one(plan["m_arr"]),
+                            one(plan["v_arr"]), (C.c_int64 * 1)(plan["sizes"][i]),
+                            int(plan["steps"][i].item()), float(group["lr"]), float(beta1),
+                            float(beta2), float(group["eps"]), stream))
         return loss
+
+    def load_state_dict(self, state_dict):
+        self.__dict__.pop("_plans", None)
+        return super().load_state_dict(state_dict)

@@ -124,6 +124,8 @@ class Trainer(object):
                 break
         if hook is not None:
             hook.remove()
+        if self.use_cuda and isinstance(self.model, ExplaiNN) and self.model.validate_input:
+            self._check_input_flags()
         self.logger.handlers.clear()
         self._train_logger.handlers.clear()
         self._validation_logger.handlers.clear()
@@ -148,7 +150,8 @@ class Trainer(object):
     def train(self):
         """One optimisation step on one mini-batch; returns nothing, logs like the reference."""
         t_i = time()
-        self.model.train()
+        if not self.model.training:          # selene/__init__.py:283 (a 17-module walk when repeated)
+            self.model.train()
         inputs, targets = self._get_batch("train")
         if self.use_cuda:
             inputs = inputs.cuda()
@@ -166,8 +169,11 @@ class Trainer(object):
             eng.attach_grads()
             self.optimizer.step()
             loss_value = loss.item()
-            if self.model.validate_input and self.model.input_flags() & 1:
-                raise ValueError("input is not one-hot (see explainn_amd.ExplaiNN.forward)")
+            # the device-side input validation flag is sticky: reading it (a second device-to-host
+            # round trip) on the first steps and then every 64th reports a non-one-hot input without
+            # paying for the check on every step; train_and_validate() reads it once more at the end
+            if self.model.validate_input and (self.step <= 3 or self.step % 64 == 0):
+                self._check_input_flags()
         else:
             predictions = self.model(inputs)
             loss = self.criterion(predictions, targets)
@@ -184,6 +190,10 @@ class Trainer(object):
             self._train_logger.log(10, np.average(self._train_loss))
             self._time_per_step = []
             self._train_loss = []
+
+    def _check_input_flags(self):
+        if self.model.input_flags() & 1:
+            raise ValueError("input is not one-hot (see explainn_amd.ExplaiNN.forward)")
 
     def _evaluate_on_data(self, which_data):
         """Average loss + all predictions/targets over a data set (selene/__init__.py:310-342)."""

@@ -152,3 +152,27 @@ def test_codes_helpers_roundtrip():
                           sq.rc_one_hot_encoding_many(sq.one_hot_encode_many(seqs)))
     with pytest.raises(ValueError):
         sq.encode_codes_many(["ACG", "AC"])
+
+
+def test_batched_loader_yields_what_the_stock_loader_yields():
+    """train._get_data_loader cuts batches with one index op; order and contents must be those of
+    the reference's DataLoader(TensorDataset(...), batch_size, shuffle) under the same RNG state."""
+    import torch
+    from torch.utils.data import DataLoader, TensorDataset
+    from explainn_amd.train import _get_data_loader
+    rng = np.random.default_rng(0)
+    seqs = rng.random((37, 4, 11)).astype(np.float32)
+    labels = rng.random((37, 2)).astype(np.float32)
+    for shuffle in (False, True):
+        torch.manual_seed(5)
+        ours = _get_data_loader(seqs, labels, batch_size=12, shuffle=shuffle)
+        assert isinstance(ours, DataLoader) and len(ours.dataset) == 37
+        got = [b for _ in range(2) for b in ours]                       # two epochs
+        torch.manual_seed(5)
+        ref = DataLoader(TensorDataset(torch.Tensor(seqs), torch.Tensor(labels)), ours.batch_size,
+                         shuffle=shuffle)
+        want = [b for _ in range(2) for b in ref]
+        assert len(got) == len(want) == 2 * len(ours)
+        for (gx, gy), (wx, wy) in zip(got, want):
+            assert torch.equal(gx, wx) and torch.equal(gy, wy)
+    assert ours.batch_size == 11                  # 37 % 12 == 1: shrunk so that no batch has one sample
