@@ -57,9 +57,22 @@ class FusedAdam(torch.optim.Adam):
         plan = {"params": list(params), "grads": grads, "steps": steps, "ms": ms, "vs": vs, "n": n,
                 "p_arr": arr(params), "g_arr": arr(grads), "m_arr": arr(ms), "v_arr": arr(vs),
                 "sizes": (C.c_int64 * n)(*[p.numel() for p in params]),
-                "uniform": len({float(t) for t in steps}) == 1}
+                "uniform": len({float(t) for t in steps}) == 1, "count": int(steps[0].item())}
+        self._sync_steps()                # an older plan of this group may hold a newer count
+        plan["count"] = int(steps[0].item())
         self._plans[gi] = plan
         return plan
+
+    def _sync_steps(self):
+        """Write the Python-side step counts into the state's `step` tensors."""
+        for plan in self.__dict__.get("_plans", {}).values():
+            if plan["uniform"]:
+                for t in plan["steps"]:
+                    t.fill_(float(plan["count"]))
+
+    def state_dict(self):
+        self._sync_steps()
+        return super().state_dict()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -69,6 +82,7 @@ class FusedAdam(torch.optim.Adam):
                 loss = closure()
         groups = [(g, [p for p in g["params"] if p.grad is not None]) for g in self.param_groups]
         if not all(self._fusable(g, ps) for g, ps in groups):
+            self._sync_steps()
             self.__dict__.pop("_plans", None)
             super().step()
             return loss
@@ -81,13 +95,20 @@ class FusedAdam(torch.optim.Adam):
             st0 = self.state[params[0]]
             if st0["exp_avg"] is not plan["ms"][0] or st0["step"] is not plan["steps"][0] or \
                     any(not g.is_contiguous() for g in plan["grads"]):
+                self._sync_steps()
                 self._plans.pop(gi, None)
                 plan = self._plan(gi, group, params)
                 if any(not g.is_contiguous() for g in plan["grads"]):
+                    self._sync_steps()
                     self.__dict__.pop("_plans", None)
                     super().step()
                     return loss
-            torch._foreach_add_(plan["steps"], 1)
+            # the step count lives in a Python int between steps; the per-parameter `step` tensors
+            # (torch's state layout) are brought up to date when the state is read (_sync_steps)
+            if plan["uniform"]:
+                plan["count"] += 1
+            else:
+                torch._foreach_add_(plan["steps"], 1)
             beta1, beta2 = group["betas"]
             dev = params[0].device
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
@@ -95,7 +116,7 @@ class FusedAdam(torch.optim.Adam):
                 if plan["uniform"]:
                     _lib.check(lib.explainn_adam_step(
                         plan["n"], plan["p_arr"], plan["g_arr"], plan["m_arr"], plan["v_arr"],
-                        plan["sizes"], int(plan["steps"][0].item()), float(group["lr"]), float(beta1),
+                        plan["sizes"], plan["count"], float(group["lr"]), float(beta1),
                         float(beta2), float(group["eps"]), stream))
                 else:
                     # parameters added later carry their own step count: one launch per tensor
@@ -111,3 +132,9 @@ class FusedAdam(torch.optim.Adam):
     def load_state_dict(self, state_dict):
         self.__dict__.pop("_plans", None)
         return super().load_state_dict(state_dict)
+
+    def add_param_group(self, param_group):
+        if "_plans" in self.__dict__:
+            self._sync_steps()
+            self.__dict__.pop("_plans", None)
+        return super().add_param_group(param_group)

@@ -160,7 +160,13 @@ class Trainer(object):
             inputs, targets = parallel.shard_batch(inputs, targets)
         if self._fused_step_available():
             eng = self._fused_engine(inputs.shape[0])
-            eng.refresh_params()
+            # parameters are re-pointed only outside the loop (train.py:318-324 re-assigns the filter
+            # bank before training; the optimiser updates in place): rebuild the pointer table when
+            # the first parameter moved, and every 64th step as a safety net
+            w0 = self.model.linears[0].weight
+            if self.step % 64 == 1 or getattr(self, "_w0_ptr", None) != w0.data_ptr():
+                eng.refresh_params()
+                self._w0_ptr = w0.data_ptr()
             _, loss = eng.step(inputs.float().contiguous(), targets.float().contiguous(),
                                seed=int(torch.randint(0, 2 ** 62, (1,)).item()),
                                freeze_top_n_filters=self.freeze_top_n_filters)
@@ -168,7 +174,10 @@ class Trainer(object):
                 self._grad_sync()       # one all-reduce of the flat buffer
             eng.attach_grads()
             self.optimizer.step()
-            loss_value = loss.item()
+            # The reference reads loss.item() here, stalling the host on the device every step; the
+            # values are only consumed when the running mean is reported, so the fused path keeps
+            # them on the device until then (or until 256 have piled up) and the host runs ahead.
+            loss_value = loss.clone()
             # the device-side input validation flag is sticky: reading it (a second device-to-host
             # round trip) on the first steps and then every 64th reports a non-one-hot input without
             # paying for the check on every step; train_and_validate() reads it once more at the end
@@ -182,14 +191,25 @@ class Trainer(object):
             self.optimizer.step()
             loss_value = loss.item()
         self._train_loss.append(loss_value)
+        if len(self._train_loss) % 256 == 0:
+            self._settle_train_loss()
         self._time_per_step.append(time() - t_i)
         if self.step > 0 and self.step % self.nth_step_report_stats == 0:
+            self._settle_train_loss()
             self.logger.info("[STEP %d] average number of steps per second: %s" % (
                 self.step, 1. / np.average(self._time_per_step)))
             self.logger.info("Training loss: %s" % np.average(self._train_loss))
             self._train_logger.log(10, np.average(self._train_loss))
             self._time_per_step = []
             self._train_loss = []
+
+    def _settle_train_loss(self):
+        """Turn the loss values still held as device tensors into floats (one transfer)."""
+        pending = [i for i, v in enumerate(self._train_loss) if torch.is_tensor(v)]
+        if pending:
+            vals = torch.cat([self._train_loss[i].reshape(1) for i in pending]).tolist()
+            for i, v in zip(pending, vals):
+                self._train_loss[i] = v
 
     def _check_input_flags(self):
         if self.model.input_flags() & 1:
