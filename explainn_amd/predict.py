@@ -27,36 +27,39 @@ def _load_model(model_file):
     return model
 
 
+_CHUNK = 4096        # sequences per device pass of predict()
+
+
 def predict(model, Xs, batch_size=100, apply_sigmoid=False):
-    """Xs: (N,4,L) one-hot (numpy or tensor, host) -- or (N,L) uint8 base codes
+    """predict.py:75-94: eval-mode logits of both strands and their mean and max, (N, T, 4) float64
+    in the order [Fwd, Rev, Mean, Max].
+
+    Xs: (N,4,L) one-hot (numpy or tensor, host) -- or (N,L) uint8 base codes
     (sequence.encode_codes_many), in which case the reverse strand is read on the fly from the same
-    bytes.  Returns (N, T, 4) float64."""
+    bytes.  In eval mode a sequence's output does not depend on what else is in its batch, so the
+    device passes use max(batch_size, 4096) sequences whatever `batch_size` says (the reference's
+    default of 100 would leave the GPU waiting on the host), with one transfer back per pass; the
+    numbers are the same as with batches of `batch_size`."""
+    from .architectures import BaseCodes
     device = model.final.weight.device
-    Xs_np = np.asarray(Xs)
-    if Xs_np.dtype == np.uint8 and Xs_np.ndim == 2:
-        from .architectures import BaseCodes
-        codes = torch.from_numpy(np.ascontiguousarray(Xs_np))
-        out = np.empty((len(codes), model._options["n_features"], 4))
-        with torch.no_grad():
-            for i in range(0, len(codes), batch_size):
-                cb = codes[i:i + batch_size].to(device)
-                fwd = model(BaseCodes(cb)).cpu().numpy()[:, :, None]
-                rev = model(BaseCodes(cb, reverse_complement=True)).cpu().numpy()[:, :, None]
-                fr = np.concatenate((fwd, rev), axis=2)
-                out[i:i + fwd.shape[0]] = np.concatenate(
-                    (fwd, rev, fr.mean(axis=2, keepdims=True), fr.max(axis=2, keepdims=True)), axis=2)
-        return torch.sigmoid(torch.Tensor(out)).numpy() if apply_sigmoid else out
-    Xs = torch.as_tensor(Xs_np, dtype=torch.float32)
-    out = np.empty((len(Xs), model._options["n_features"], 4))
+    Xs_np = Xs if torch.is_tensor(Xs) else np.asarray(Xs)
+    as_codes = (Xs_np.dtype in (np.uint8, torch.uint8)) and Xs_np.ndim == 2
+    if as_codes:
+        data = torch.as_tensor(np.ascontiguousarray(Xs_np)) if not torch.is_tensor(Xs_np) else Xs_np
+    else:
+        data = torch.as_tensor(Xs_np, dtype=torch.float32)
+    chunk = max(int(batch_size), _CHUNK)
+    out = np.empty((len(data), model._options["n_features"], 4))
     with torch.no_grad():
-        for i in range(0, len(Xs), batch_size):
-            fwd_x = Xs[i:i + batch_size].to(device)
-            rev_x = torch.flip(fwd_x, dims=(1, 2))            # rc_one_hot_encoding: both axes
-            fwd = model(fwd_x).cpu().numpy()[:, :, None]
-            rev = model(rev_x).cpu().numpy()[:, :, None]
-            fr = np.concatenate((fwd, rev), axis=2)
-            out[i:i + fwd.shape[0]] = np.concatenate(
-                (fwd, rev, fr.mean(axis=2, keepdims=True), fr.max(axis=2, keepdims=True)), axis=2)
+        for i in range(0, len(data), chunk):
+            xb = data[i:i + chunk].to(device)
+            if as_codes:
+                fwd, rev = model(BaseCodes(xb)), model(BaseCodes(xb, reverse_complement=True))
+            else:
+                fwd, rev = model(xb), model(torch.flip(xb, dims=(1, 2)))   # rc_one_hot_encoding: both axes
+            # numpy's float32 mean of two values is (a + b) / 2 in float32, as here
+            both = torch.stack((fwd, rev, (fwd + rev) / 2, torch.maximum(fwd, rev)), dim=2)
+            out[i:i + both.shape[0]] = both.cpu().numpy()
     if apply_sigmoid:
         out = torch.sigmoid(torch.Tensor(out)).numpy()
     return out

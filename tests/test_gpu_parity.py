@@ -62,6 +62,12 @@ def test_eval_forward_golden(golden):
         pred = np.concatenate([fwd_rev, fwd_rev.mean(2, keepdims=True),
                                fwd_rev.max(2, keepdims=True)], axis=2)
         _close(pred, g.z["eval/predict"], what="predict Fwd/Rev/Mean/Max")
+    # the predict entry point (one chunked device pass, one transfer back) gives the same table
+    from explainn_amd.predict import predict
+    table = predict(m, g.onehot(), batch_size=3)
+    assert table.dtype == np.float64 and table.shape == g.z["eval/predict"].shape
+    _close(table, g.z["eval/predict"], what="predict()")
+    assert np.array_equal(table, pred.astype(np.float64))
 
 
 def _train_once(g, keep=None):

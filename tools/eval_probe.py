@@ -19,3 +19,15 @@ for B in (100, 1024, 4096):
             for _ in range(K): m(inp)
             torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
         print("eval B=%-5d %-9s %.3f ms/batch  %.2f M seq/s" % (B, name, dt * 1e3, B / dt / 1e6), flush=True)
+
+# the predict entry point on host data (N = 20000), reference default batch size
+import numpy as np
+from explainn_amd.predict import predict
+from explainn_amd import sequence as sq
+N = 20000
+idx = np.random.default_rng(0).integers(0, 4, size=(N, L)).astype(np.uint8)
+xh = sq.codes_to_one_hot(idx)
+for name, inp in (("one-hot", xh), ("codes", idx)):
+    predict(m, inp[:512], batch_size=100)
+    t0 = time.perf_counter(); predict(m, inp, batch_size=100); dt = time.perf_counter() - t0
+    print("predict() %-8s N=%d batch_size=100: %.1f ms, %.2f M seq/s (both strands)" % (name, N, dt * 1e3, N / dt / 1e6), flush=True)
