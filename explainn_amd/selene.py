@@ -220,16 +220,19 @@ class Trainer(object):
         self.model.eval()
         batch_losses, all_predictions, all_targets = [], [], []
         for inputs, targets in iter(self.data_loaders[which_data]):
+            all_targets.append(targets.data.cpu().numpy())       # already on the host: no round trip
             if self.use_cuda:
                 inputs = inputs.cuda()
                 targets = targets.cuda()
             with torch.no_grad():
                 predictions = self.model(inputs)
-                loss = self.criterion(predictions, targets)
-                all_predictions.append(predictions.data.cpu().numpy())
-                batch_losses.append(loss.item())
-            all_targets.extend(targets.data.cpu().numpy())
-        return (np.average(batch_losses), np.vstack(all_predictions), np.vstack(all_targets))
+                # kept on the device; the reference's per-batch .cpu()/.item() reads are done once,
+                # after the loop
+                batch_losses.append(self.criterion(predictions, targets).reshape(1))
+                all_predictions.append(predictions.data)
+        losses = torch.cat(batch_losses).tolist() if batch_losses else []
+        preds = torch.cat(all_predictions).cpu().numpy() if all_predictions else np.zeros((0, 0))
+        return (np.average(losses), preds, np.vstack(all_targets))
 
     def validate(self):
         """Validation metrics on flattened predictions; best model -> best_model.pth.tar
