@@ -48,7 +48,10 @@ def _as_tensor(Xs):
 
 
 def _get_outs_preds(exp_model, Xs, batch_size=100):
-    """The (N,U) unit outputs and (N,T) predictions of test.py:128-166, float16 like there."""
+    """The (N,U) unit outputs and (N,T) predictions of test.py:128-166, float16 like there.
+    Eval-mode outputs do not depend on batch composition, so the device passes take at least 4096
+    sequences whatever batch_size says."""
+    batch_size = max(int(batch_size), 4096)
     dev = exp_model.final.weight.device
     U, T = exp_model._options["cnn_units"], exp_model._options["n_features"]
     outputs = np.zeros((len(Xs), U), dtype=np.float16)
@@ -192,7 +195,7 @@ def interpret(exp_model, seqs, labels, name, output_dir="./", batch_size=100, re
         os.path.join(output_dir, "output-layer-weights.tsv"), sep="\t", index=False)
     outs, preds = _get_outs_preds(exp_model, seqs, batch_size)
     idxs = _get_well_predicted_sequences(preds, labels, input_data, rev_complement)
-    res = filter_pwms(exp_model, seqs, idxs, rev_complement, batch_size=max(batch_size, 256))
+    res = filter_pwms(exp_model, seqs, idxs, rev_complement, batch_size=max(batch_size, 4096))
     data = []
     for u, (_, imps) in enumerate(filter_importances(outs, weights, idxs, res["hit"])):
         data.extend([["filter%d" % u] + col.tolist() for col in imps.T])
