@@ -185,6 +185,9 @@ def test_adam_trajectory_golden(golden):
     (37, 19, 61, 50, 70, 0.02),     # T = 50 (C3/C4): combiner forward/backward as MFMA GEMMs
     (70, 9, 40, 164, 131, 0.0),     # T = 164 (C5), ragged tiles in every GEMM dimension
     (3, 5, 33, 9, 5, 0.0),          # smallest GEMM case: one partly filled tile
+    (6, 32, 120, 1, 40, 0.03),      # largest instantiated kernel size (two code words per window)
+    (5, 2, 40, 2, 33, 0.05),        # smallest kernel size
+    (4, 31, 260, 1, 20, 0.02),      # odd kernel size next to the maximum, two staging chunks (n = 32+)
 ])
 def test_train_step_vs_oracle(U, k, L, T, B, nfrac):
     sd = orc.random_state_dict(U, k, L, T, seed=U + L)
