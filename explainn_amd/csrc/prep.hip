@@ -185,15 +185,28 @@ __global__ __launch_bounds__(64) void qmom_kernel(
             for (int i = 0; i < (NWT > 1 ? 32 : 1); ++i) tB[i * QT_LD + lane] = rb[i];
         }
         if (b0 + 64 < bend) fetch(b0 + 64);           // in flight during the MFMAs below
-        const int ks = (min(bend - b0, 64) + 1) >> 1;
         const float* srcB = (NWT > 1 && !same) ? tB : tA;
-        for (int s = 0; s < ks; ++s) {
-            const int col = 2 * s + kk;
-            const bool live = b0 + col < bend;
-            const float a = (live && wt * 32 + rc < n) ? tA[rc * QT_LD + col] - sA : 0.f;
-            const float bq = (live && wB < n) ? srcB[rc * QT_LD + col] - sB : 0.f;
-            s1 += bq;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc, 0, 0, 0);
+        // Always the full 32 k-steps of a super-tile, eight at a time with their LDS operands read
+        // first (columns past the chunk end are zero): with a runtime trip count every step was
+        // "read LDS, wait, one MFMA" -- ~440 cycles each instead of the MFMA's 64.
+#pragma unroll
+        for (int s0 = 0; s0 < 32; s0 += 8) {
+            float av[8], bv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int col = 2 * (s0 + q) + kk;
+                av[q] = tA[rc * QT_LD + col];
+                bv[q] = (NWT > 1 && !same) ? srcB[rc * QT_LD + col] : av[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int col = 2 * (s0 + q) + kk;
+                const bool live = b0 + col < bend;
+                const float a = (live && wt * 32 + rc < n) ? av[q] - sA : 0.f;
+                const float bq = (live && wB < n) ? bv[q] - sB : 0.f;
+                s1 += bq;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc, 0, 0, 0);
+            }
         }
     }
     STAMP(2);
