@@ -12,6 +12,8 @@
 //   fin_bwd   per unit: BN1 backward closed form -> dW, d gamma1, d beta1.
 #include "common.h"
 
+typedef float f32x16b __attribute__((ext_vector_type(16)));
+
 // n <= 72: one 1024-thread block per unit with V1, A2, EQ and M
 // staged in LDS, so every inner loop reads LDS instead of chasing dependent global loads.
 __global__ __launch_bounds__(1024) void mid_fused_kernel(
@@ -84,23 +86,50 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
     }
     __syncthreads();
     STAMP(2);
-    for (int e = tid; e < NS * NS; e += 1024) {
-        const int v = e / NS, w = e % NS;
-        float acc = 0.f;
-        if (v < n && w < n) {
-            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;    // four independent chains over r
-            for (int r = 0; r < FC_H; r += 4) {
-                a0 = fma((double)(cfs[r] * V1s[r * ld + v]), (double)A2s[r * ld + w], a0);
-                a1 = fma((double)(cfs[r + 1] * V1s[(r + 1) * ld + v]), (double)A2s[(r + 1) * ld + w], a1);
-                a2 = fma((double)(cfs[r + 2] * V1s[(r + 2) * ld + v]), (double)A2s[(r + 2) * ld + w], a2);
-                a3 = fma((double)(cfs[r + 3] * V1s[(r + 3) * ld + v]), (double)A2s[(r + 3) * ld + w], a3);
+    // M[v][w] = sum_r cf[r] V1[r][v] A2[r][w] on the fp32 MFMA (its consumer passB is fp32): one 32x32
+    // tile per wave, K = 100 channels = 50 steps, LDS operands read ten steps ahead.  (As an fp64
+    // VALU loop this phase was LDS-latency bound: 10 K cycles of the block's 36 K.)
+    {
+        const int wave = tid >> 6, lane = tid & 63, rc = lane & 31, kk = lane >> 5;
+        const int NT2 = (NS + 31) >> 5;
+        // one wave per tile (splitting the single tile of n <= 32 over four waves with an LDS
+        // reduction made the isolated kernel faster and the pipeline 5 us slower: not kept)
+        for (int tile = wave; tile < NT2 * NT2; tile += 16) {
+            const int vt = tile / NT2, wt = tile % NT2;
+            const int va = 32 * vt + rc, wb = 32 * wt + rc;
+            const bool alive = va < n, blive = wb < n;
+            const float* acol = V1s + min(va, n - 1);
+            const float* bcol = A2s + min(wb, n - 1);
+            f32x16b acc;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+#pragma unroll
+            for (int s0 = 0; s0 < FC_H / 2; s0 += 10) {
+                float av[10], bv[10];
+#pragma unroll
+                for (int q = 0; q < 10; ++q) {
+                    const int r = 2 * (s0 + q) + kk;
+                    av[q] = cfs[r] * acol[r * ld];
+                    bv[q] = bcol[r * ld];
+                }
+#pragma unroll
+                for (int q = 0; q < 10; ++q)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(alive ? av[q] : 0.f, blive ? bv[q] : 0.f,
+                                                               acc, 0, 0, 0);
             }
-            acc = (float)((a0 + a1) + (a2 + a3));
-            Ms[v * n + w] = acc;
+            if (wb < NS) {
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int v = 32 * vt + (g & 3) + 8 * (g >> 2) + 4 * kk;
+                    if (v < NS) {
+                        M[(size_t)u * NS * NS + (size_t)v * NS + wb] = acc[g];
+                        if ((v >> 1) < NKS)
+                            Mff[(size_t)u * NWT * NKS * 64 + ((size_t)(wb >> 5) * NKS + (v >> 1)) * 64 + (v & 1) * 32 + (wb & 31)] = acc[g];
+                        if (v < n && wb < n) Ms[v * n + wb] = acc[g];
+                    }
+                }
+            }
         }
-        M[(size_t)u * NS * NS + e] = acc;
-        if ((v >> 1) < NKS)
-            Mff[(size_t)u * NWT * NKS * 64 + ((size_t)(w >> 5) * NKS + (v >> 1)) * 64 + (v & 1) * 32 + (w & 31)] = acc;
     }
     STAMP(3);
     for (int e = tid; e < FC_H * NS; e += 1024) {
@@ -139,8 +168,6 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
 // (2 x 100 x (n+1) floats), the EQ sums go through global memory (EQs), C is streamed through LDS in
 // 32-column chunks, and the k0' correction uses  sum_v qbar[v] M[v][w] = sum_r cf[r] (V1[r].qbar) A2[r][w]
 // so M itself never has to be resident.
-typedef float f32x16b __attribute__((ext_vector_type(16)));
-
 __global__ __launch_bounds__(1024) void mid_big_kernel(
     const float* __restrict__ EQp, const float* __restrict__ Sep, const float* __restrict__ A2,
     const float* __restrict__ sh2, const float* __restrict__ sig2, const float* __restrict__ fc1_w,
