@@ -343,8 +343,6 @@ static size_t prep2_lds(int n, int NS) {
     return (size_t)NS * sizeof(double) + ((size_t)n * n + (size_t)FC_H * (n + 1)) * sizeof(float);
 }
 
-constexpr int PREP2_MFMA_MIN_N = 72;   // above this the V1.C product runs on the MFMA (fp32)
-
 template <bool TRAIN>
 __global__ __launch_bounds__(1024) void prep2_kernel(
     const float* __restrict__ fc1_w, const float* __restrict__ fc1_b,
@@ -410,9 +408,11 @@ __global__ __launch_bounds__(1024) void prep2_kernel(
         const int rr = r < FC_H ? r : FC_H - 1;
         const float* v1 = V1s + rr * ld;
         double var = 0;
-        if (n > PREP2_MFMA_MIN_N) {
-            // large n: VC = V1 . C on the matrix cores (fp32 MFMA, 32x32 tiles: 4 row tiles of hidden
-            // channels x NWT column tiles, K = n in steps of 2), one tile per wave per pass
+        {
+            // VC = V1 . C on the matrix cores (fp32 MFMA, 32x32 tiles: 4 row tiles of hidden channels
+            // x NWT column tiles, K = n in steps of 2), one tile per wave per pass.  The product is
+            // also what the backward needs (hq in the mid kernels), so it goes to global memory.
+            // (An fp64 VALU version of this quadratic form was LDS-latency bound: 4 us per step more.)
             const int wave = tid >> 6, lane = tid & 63, rc = lane & 31, kk = lane >> 5;
             const int NWT = (n + 31) >> 5;
             for (int tile = wave; tile < 4 * NWT; tile += NT / 64) {
@@ -424,11 +424,20 @@ __global__ __launch_bounds__(1024) void prep2_kernel(
                 f32x16q acc;
 #pragma unroll
                 for (int g = 0; g < 16; ++g) acc[g] = 0.f;
-                for (int s2 = 0; s2 < (n + 1) / 2; ++s2) {
-                    const int w = 2 * s2 + kk, wc = min(w, n - 1);
-                    const float a = (alive && w < n) ? arow[wc] : 0.f;
-                    const float b = (blive && w < n) ? bcol[wc * n] : 0.f;
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+                for (int s0 = 0; s0 < (n + 1) / 2; s0 += 4) {     // four k-steps per pass, operands first
+                    float av[4], bv[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int wc = min(2 * (s0 + q) + kk, n - 1);
+                        av[q] = arow[wc];
+                        bv[q] = bcol[wc * n];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bool on = 2 * (s0 + q) + kk < n;
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32((alive && on) ? av[q] : 0.f,
+                                                                   (blive && on) ? bv[q] : 0.f, acc, 0, 0, 0);
+                    }
                 }
                 if (blive) {
 #pragma unroll
@@ -441,27 +450,6 @@ __global__ __launch_bounds__(1024) void prep2_kernel(
             __syncthreads();                  // this block's VC writes are visible to its own reads
             for (int wp = part; wp < n; wp += 8)
                 var = fma((double)VC[((size_t)u * FC_H + rr) * NS + wp], (double)v1[wp], var);
-        } else {
-            // four columns w' per pass: independent fma chains instead of one 26..160-long chain
-            for (int wp0 = part; wp0 < n; wp0 += 32) {
-                int wpi[4];
-                double t[4] = {0, 0, 0, 0};
-    #pragma unroll
-                for (int i = 0; i < 4; ++i) wpi[i] = min(wp0 + 8 * i, n - 1);
-                for (int w = 0; w < n; ++w) {
-                    const double v = (double)v1[w];
-                    const float* crow = Cs + w * n;
-    #pragma unroll
-                    for (int i = 0; i < 4; ++i) t[i] = fma(v, (double)crow[wpi[i]], t[i]);
-                }
-    #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (wp0 + 8 * i < n) {
-                        var = fma(t[i], (double)v1[wpi[i]], var);
-                        // V1.C is also what the backward needs (hq in the mid kernels): keep it
-                        if (r < FC_H) VC[((size_t)u * FC_H + r) * NS + wpi[i]] = (float)t[i];
-                    }
-            }
         }
         var += __shfl_xor(var, 1, 64); var += __shfl_xor(var, 2, 64); var += __shfl_xor(var, 4, 64);
         const int ch = u * FC_H + rr;
