@@ -132,7 +132,12 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
         }
     }
     STAMP(3);
-    for (int e = tid; e < FC_H * NS; e += 1024) {
+    // dV1 and T do not need M: the waves that had no M tile above do this loop while the tile waves
+    // are still in their MFMA chains (with everybody taking an equal share the block waited for
+    // wave 0 to finish its tile AND its share)
+    const int busy = min(((NS + 31) >> 5) * ((NS + 31) >> 5), 8) * 64;     // threads of the tile waves
+    for (int e = tid - busy; e < FC_H * NS; e += 1024 - busy) {
+        if (e < 0) break;                              // tile waves skip
         const int r = e / NS, w = e % NS;
         const size_t ch = (size_t)u * FC_H + r;
         const double sv = sc * (double)fc2_w[ch];
