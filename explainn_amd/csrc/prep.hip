@@ -464,7 +464,12 @@ __global__ __launch_bounds__(1024) void prep2_kernel(
                 shp = fma((double)a, qb[w], shp);
                 meanp = fma((double)v1[w], qb[w], meanp);
             }
-            if (r < FC_H) A2[(size_t)ch * NS + w] = a;
+            if (r < FC_H) {
+                A2[(size_t)ch * NS + w] = a;
+                // this (channel, w) is this thread's alone: V1's LDS copy now carries A2, which the
+                // fragment emission below reads instead of going back to global memory
+                if (w < n) V1s[rr * ld + w] = a;
+            }
         }
         shp += __shfl_xor(shp, 1, 64); shp += __shfl_xor(shp, 2, 64); shp += __shfl_xor(shp, 4, 64);
         meanp += __shfl_xor(meanp, 1, 64); meanp += __shfl_xor(meanp, 2, 64);
@@ -483,11 +488,13 @@ __global__ __launch_bounds__(1024) void prep2_kernel(
     // the same weights in MFMA A-fragment order for fc_fwd:
     // A2f[((t*NKS + s)*64) + l] = A2[32t + (l&31)][2s + (l>>5)]
     __syncthreads();
+    const float* a2lds = TRAIN ? reinterpret_cast<const float*>(sm + NS) + n * n : nullptr;   // = V1s
     for (int i = tid; i < 4 * NKS * 64; i += NT) {
         const int l = i & 63, s = (i >> 6) % NKS, t = (i >> 6) / NKS;
         const int r = 32 * t + (l & 31), w = 2 * s + (l >> 5);
-        A2f[(size_t)u * 4 * NKS * 64 + i] =
-            (r < FC_H && w < n) ? A2[((size_t)u * FC_H + r) * NS + w] : 0.f;
+        float v = 0.f;
+        if (r < FC_H && w < n) v = TRAIN ? a2lds[r * (n + 1) + w] : A2[((size_t)u * FC_H + r) * NS + w];
+        A2f[(size_t)u * 4 * NKS * 64 + i] = v;
     }
     STAMP(3);
 }
