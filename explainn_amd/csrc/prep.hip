@@ -369,12 +369,33 @@ __global__ __launch_bounds__(1024) void prep2_kernel(
         float* V1s = Cs + n * n;
         const int ld = n + 1;
         const double invB = 1.0 / (double)B;
-        for (int e = tid; e < FC_H * n; e += NT)
-            V1s[(e / n) * ld + (e % n)] = fc1_w[(size_t)u * FC_H * n + e];
-        // combine the chunk partials (fixed order -> deterministic)
-        for (int w = tid; w < n; w += NT) {
+        // V1 into LDS, four elements per thread per pass with their loads issued together (a plain
+        // strided loop with a runtime trip count is one exposed round trip per iteration)
+        for (int e0 = tid; e0 < FC_H * n; e0 += 4 * NT) {
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = fc1_w[(size_t)u * FC_H * n + min(e0 + q * NT, FC_H * n - 1)];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) KEEP(v[q]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = e0 + q * NT;
+                if (e < FC_H * n) V1s[(e / n) * ld + (e % n)] = v[q];
+            }
+        }
+        // combine the chunk partials (fixed order -> deterministic), eight loads in flight; the last
+        // threads take this so that it overlaps the staging above
+        for (int w = NT - 1 - tid; w < n; w += NT) {
             double s1 = 0;
-            for (int c = 0; c < QCH; ++c) s1 += (double)S1p[((size_t)u * QCH + c) * NS + w];
+            for (int c0 = 0; c0 < QCH; c0 += 8) {
+                float pv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) pv[i] = S1p[((size_t)u * QCH + min(c0 + i, QCH - 1)) * NS + w];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) KEEP(pv[i]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s1 += (c0 + i < QCH) ? (double)pv[i] : 0.0;
+            }
             qb[w] = s1 * invB;                // mean of (q - s); the shift is added below
         }
         __syncthreads();
