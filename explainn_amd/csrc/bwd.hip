@@ -14,6 +14,10 @@
 
 typedef float f32x16b __attribute__((ext_vector_type(16)));
 
+// Register budget: this kernel must stay at <= 64 VGPRs so that TWO 1024-thread blocks share a CU --
+// 300 units on 256 CUs otherwise take two rounds.  (Batching the per-channel partial-sum loads below
+// made the block 11 % faster in isolation, took 127 VGPRs, and cost 5 us per step in the pipeline;
+// check -Rpass-analysis=kernel-resource-usage after touching it.)
 // n <= 72: one 1024-thread block per unit with V1, A2, EQ and M
 // staged in LDS, so every inner loop reads LDS instead of chasing dependent global loads.
 __global__ __launch_bounds__(1024) void mid_fused_kernel(
