@@ -436,8 +436,8 @@ __global__ __launch_bounds__(64, 5) void conv_bwd_kernel(const float* __restrict
     for (int wc = 0; wc < n; wc += CBW) {
         // chunk origin in words: POOLW*CBW = 224 positions = 14 code words = 7 mask words
         const int w_lo = (POOLW * wc) >> 4, n_lo = (POOLW * wc) >> 5;
-        stage_column(pks + lane, pk2 + (size_t)w_lo * Bs + b, min(PWC, PW - w_lo), Bs);
-        stage_column(nms + lane, nmask + (size_t)n_lo * Bs + b, min(NWC, NW - n_lo), Bs);
+        stage_columns2<PWC, NWC>(pks + lane, pk2 + (size_t)w_lo * Bs + b, min(PWC, PW - w_lo),
+                                 nms + lane, nmask + (size_t)n_lo * Bs + b, min(NWC, NW - n_lo), Bs);
         if (wc == 0) STAMP(1);
         const int wend = min(wc + CBW, n);
         // dy / idx for two windows are requested together (more would cost the 5th wave per SIMD)

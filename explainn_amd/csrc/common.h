@@ -185,6 +185,30 @@ __device__ __forceinline__ void stage_column(uint32_t* __restrict__ tile_lane,
     }
 }
 
+// Two column tiles at once (the packed codes and the N mask of one chunk), EVERY load of both issued
+// before the first store: one exposed round trip instead of one per batch of eight.  R1/R2 are the
+// compile-time tile heights, rows1/rows2 (<= R1/R2) what the sequence still has.
+template <int R1, int R2>
+__device__ __forceinline__ void stage_columns2(uint32_t* __restrict__ t1, const uint32_t* __restrict__ s1,
+                                               int rows1, uint32_t* __restrict__ t2,
+                                               const uint32_t* __restrict__ s2, int rows2, int Bs) {
+    uint32_t a[R1], b[R2];
+#pragma unroll
+    for (int i = 0; i < R1; ++i) a[i] = s1[(size_t)min(i, rows1 - 1) * Bs];
+#pragma unroll
+    for (int i = 0; i < R2; ++i) b[i] = s2[(size_t)min(i, rows2 - 1) * Bs];
+#pragma unroll
+    for (int i = 0; i < R1; ++i) KEEP(a[i]);
+#pragma unroll
+    for (int i = 0; i < R2; ++i) KEEP(b[i]);
+#pragma unroll
+    for (int i = 0; i < R1; ++i)
+        if (i < rows1) t1[i * 64] = a[i];
+#pragma unroll
+    for (int i = 0; i < R2; ++i)
+        if (i < rows2) t2[i * 64] = b[i];
+}
+
 // The filter bank's lookup tables for unit u (all threads of the block call it): Wt (per-tap table,
 // unit-quad interleaved, entry 4 = N = zero) and lut (dinucleotide sums, unit-pair interleaved)
 // from the current filters.  wsh: 4*MAX_K floats of LDS.

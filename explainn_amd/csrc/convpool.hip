@@ -61,12 +61,28 @@ __global__ __launch_bounds__(64) void conv_pool_kernel(const uint32_t* __restric
     const int quad = pair >> 1, off = (pair & 1) * 2;
     STAMP(0);
     {
+        // both tables with all their loads in flight before the first LDS store
         const float2* src = lut + (size_t)pair * NT * 16;
-        for (int i = lane; i < NT * 16; i += 64) L2[i] = src[i];
-        for (int i = lane; i < K * 5; i += 64) {
+        constexpr int NL = (NT * 16 + 63) / 64, NWP = (K * 5 + 63) / 64;
+        float2 lv[NL], wv[NWP];
+#pragma unroll
+        for (int j = 0; j < NL; ++j) lv[j] = src[min(lane + 64 * j, NT * 16 - 1)];
+#pragma unroll
+        for (int j = 0; j < NWP; ++j) {
+            const int i = min(lane + 64 * j, K * 5 - 1);
             const float* w = Wt + ((size_t)quad * K + i / 5) * 20 + (i % 5) * 4 + off;
-            Wp[i] = make_float2(w[0], w[1]);
+            wv[j] = make_float2(w[0], w[1]);
         }
+#pragma unroll
+        for (int j = 0; j < NL; ++j) { KEEP(lv[j].x); KEEP(lv[j].y); }
+#pragma unroll
+        for (int j = 0; j < NWP; ++j) { KEEP(wv[j].x); KEEP(wv[j].y); }
+#pragma unroll
+        for (int j = 0; j < NL; ++j)
+            if (lane + 64 * j < NT * 16) L2[lane + 64 * j] = lv[j];
+#pragma unroll
+        for (int j = 0; j < NWP; ++j)
+            if (lane + 64 * j < K * 5) Wp[lane + 64 * j] = wv[j];
     }
     // sign(alpha) = sign(gamma1): the pooling direction does not need the BatchNorm statistics,
     // so this kernel can run beside the input-moment chain
@@ -81,8 +97,8 @@ __global__ __launch_bounds__(64) void conv_pool_kernel(const uint32_t* __restric
     for (int wc = wbeg; wc < wend; wc += CPW) {
     // chunk origin in words; columns are lane-private, so no barrier is needed between chunks
     const int w_lo = (POOLW * wc) >> 4, n_lo = (POOLW * wc) >> 5;
-    stage_column(pks + lane, pk2 + (size_t)w_lo * Bs + b, min(PWC, PW - w_lo), Bs);
-    stage_column(nms + lane, nmask + (size_t)n_lo * Bs + b, min(NWC, NW - n_lo), Bs);
+    stage_columns2<PWC, NWC>(pks + lane, pk2 + (size_t)w_lo * Bs + b, min(PWC, PW - w_lo),
+                             nms + lane, nmask + (size_t)n_lo * Bs + b, min(NWC, NW - n_lo), Bs);
     // window words of the chunk's first pooling window (the next one is prefetched inside the loop)
     const int wi0 = ((POOLW * wc) >> 4) - w_lo, ni0 = ((POOLW * wc) >> 5) - n_lo;
     uint32_t c0 = pl[wi0 * 64], c1 = pl[(wi0 + 1) * 64], c2 = pl[(wi0 + 2) * 64], c3 = pl[(wi0 + 3) * 64];
