@@ -9,6 +9,7 @@
 
 #define FC_H 100          // hidden width of the per-unit FC (architectures/__init__.py:86)
 #define SEED_RING 1024      // pinned host slots the per-step dropout seeds are copied from (graph replay)
+#define HEAD_RB 8            // head kernels keep up to HEAD_RB*256 sequences per unit in registers
 #define HEAD_GEMM_MIN_T 8   // more tasks than this: combiner forward/backward as MFMA GEMMs (head.hip)
 #define POOLW 7           // MaxPool1d(7,7)        (architectures/__init__.py:81)
 #define BN_EPS_D 1e-5     // architectures/__init__.py:79,90,99

@@ -107,18 +107,52 @@ __global__ __launch_bounds__(256) void head_fwd_train_kernel(
     __shared__ double red[4];
     const int u = blockIdx.x, tid = threadIdx.x;
     const float* zu = z + (size_t)u * Bs;
+    // Batches up to HEAD_RB*256 sequences keep this thread's z values in registers: one batch of loads
+    // instead of three passes of dependent round trips over the same row.
+    constexpr int RB = HEAD_RB;
+    const bool inreg = B <= RB * 256;
+    float zr[RB];
+    if (inreg) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i) zr[i] = zu[min(tid + 256 * i, B - 1)];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) KEEP(zr[i]);
+    }
     double s = 0;
-    for (int b = tid; b < B; b += 256) s += (double)zu[b];
+    if (inreg) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i) s += (tid + 256 * i < B) ? (double)zr[i] : 0.0;
+    } else {
+        for (int b = tid; b < B; b += 256) s += (double)zu[b];
+    }
     const double mean = block_sum_256(s, red) / (double)B;
     double v = 0;
-    for (int b = tid; b < B; b += 256) { const double d = (double)zu[b] - mean; v = fma(d, d, v); }
+    if (inreg) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+            if (tid + 256 * i < B) { const double d = (double)zr[i] - mean; v = fma(d, d, v); }
+    } else {
+        for (int b = tid; b < B; b += 256) { const double d = (double)zu[b] - mean; v = fma(d, d, v); }
+    }
     double var = block_sum_256(v, red) / (double)B;
     const double sg = sqrt(var + BN_EPS_D);
     const float meanf = (float)mean, isg = (float)(1.0 / sg), gam = g3[u], bet = b3[u];
-    for (int b = tid; b < B; b += 256) {
-        const float zh = (zu[b] - meanf) * isg;
-        zhat[(size_t)u * Bs + b] = zh;
-        o[(size_t)u * Bs + b] = fmaxf(fmaf(gam, zh, bet), 0.f);
+    if (inreg) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int b = tid + 256 * i;
+            if (b < B) {
+                const float zh = (zr[i] - meanf) * isg;
+                zhat[(size_t)u * Bs + b] = zh;
+                o[(size_t)u * Bs + b] = fmaxf(fmaf(gam, zh, bet), 0.f);
+            }
+        }
+    } else {
+        for (int b = tid; b < B; b += 256) {
+            const float zh = (zu[b] - meanf) * isg;
+            zhat[(size_t)u * Bs + b] = zh;
+            o[(size_t)u * Bs + b] = fmaxf(fmaf(gam, zh, bet), 0.f);
+        }
     }
     if (tid == 0) {
         sig3[u] = (float)sg;
@@ -288,23 +322,94 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
     float* dzu = dz + (size_t)u * Bs;
     const float invN = 1.0f / (float)(B * T);
     double s1 = 0, s2 = 0;
-    for (int b = tid; b < B; b += 256) {
-        float dob = 0.f;
-        if (GEMMED) dob = dzu[b];
-        else
-            for (int t = 0; t < T; ++t)
-                dob = fmaf(dl_at<FUSED>(dl, logits, y, kind, invN, b * T + t), Wf[(size_t)t * U + u], dob);
-        const float d3 = ou[b] > 0.f ? dob : 0.f;
-        dzu[b] = d3;
-        s1 += (double)d3;
-        s2 = fma((double)d3, (double)zh[b], s2);
+    // small batches and few tasks: d3 and zhat of this thread's sequences stay in registers between
+    // the two passes (one batch of loads each instead of a dependent round trip per 256 sequences)
+    constexpr int RB = HEAD_RB;
+    const bool inreg = !GEMMED && T <= 4 && B <= RB * 256;
+    float d3r[RB], zhr[RB];
+    double gw[4] = {0, 0, 0, 0}, gb[4] = {0, 0, 0, 0}, lacc = 0;
+    if (inreg) {
+        float our[RB];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int bc = min(tid + 256 * i, B - 1);
+            our[i] = ou[bc];
+            zhr[i] = zh[bc];
+            const bool live_i = tid + 256 * i < B;
+            float dob = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t >= T) continue;
+                const float dlv = dl_at<FUSED>(dl, logits, y, kind, invN, bc * T + t);
+                dob = fmaf(dlv, Wf[(size_t)t * U + u], dob);
+                // the final-layer gradients ride along: d Wf[t][u] += dl * o, and (unit 0's block)
+                // d bf[t] += dl and the loss value
+                if (live_i) {
+                    gw[t] = fma((double)dlv, (double)our[i], gw[t]);
+                    if (u == 0) {
+                        gb[t] += (double)dlv;
+                        if (FUSED) {
+                            const float x = logits[bc * T + t], tt = y[bc * T + t];
+                            float l;
+                            if (kind == EXPLAINN_LOSS_BCE_WITH_LOGITS) l = fmaxf(x, 0.f) - x * tt + log1pf(expf(-fabsf(x)));
+                            else { const float e = x - tt; l = e * e; }
+                            lacc += (double)l;
+                        }
+                    }
+                }
+            }
+            d3r[i] = dob;
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const bool live = tid + 256 * i < B;
+            d3r[i] = (live && our[i] > 0.f) ? d3r[i] : 0.f;
+            s1 += (double)d3r[i];
+            s2 = fma((double)d3r[i], live ? (double)zhr[i] : 0.0, s2);
+        }
+    } else {
+        for (int b = tid; b < B; b += 256) {
+            float dob = 0.f;
+            if (GEMMED) dob = dzu[b];
+            else
+                for (int t = 0; t < T; ++t)
+                    dob = fmaf(dl_at<FUSED>(dl, logits, y, kind, invN, b * T + t), Wf[(size_t)t * U + u], dob);
+            const float d3 = ou[b] > 0.f ? dob : 0.f;
+            dzu[b] = d3;
+            s1 += (double)d3;
+            s2 = fma((double)d3, (double)zh[b], s2);
+        }
     }
     const double S1 = block_sum_256(s1, red);
     const double S2 = block_sum_256(s2, red);
     const float m1 = (float)(S1 / (double)B), m2 = (float)(S2 / (double)B);
     const float sc = g3[u] / sig3[u];
-    for (int b = tid; b < B; b += 256) dzu[b] = sc * (dzu[b] - m1 - zh[b] * m2);
+    if (inreg) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+            if (tid + 256 * i < B) dzu[tid + 256 * i] = sc * (d3r[i] - m1 - zhr[i] * m2);
+    } else {
+        for (int b = tid; b < B; b += 256) dzu[b] = sc * (dzu[b] - m1 - zh[b] * m2);
+    }
     if (tid == 0) { gg3[u] = (float)S2; gb3[u] = (float)S1; gc2[u] = 0.f; }
+    if (inreg) {
+        // everything was accumulated in the first pass; only the block-wide sums are left
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t >= T) continue;                      // T is block-uniform: the barriers inside stay uniform
+            const double tot = block_sum_256(gw[t], red);
+            if (tid == 0) gWf[(size_t)t * U + u] = (float)tot;
+            if (u == 0) {
+                const double ct = block_sum_256(gb[t], red);
+                if (tid == 0) gbf[t] = (float)ct;
+            }
+        }
+        if (FUSED && u == 0) {
+            const double tot = block_sum_256(lacc, red);
+            if (tid == 0) *loss_out = (float)(tot / (double)(B * T));
+        }
+        return;
+    }
     for (int t = 0; t < (GEMMED ? 0 : T); ++t) {
         double a = 0;
         for (int b = tid; b < B; b += 256)
