@@ -360,29 +360,30 @@ __device__ __forceinline__ void fin_unit(const fin_args& f, const float* __restr
     const int K4 = f.K4;
     const int NT = Bs / 64, nt = (B + 63) / 64;
     const int NT32 = Bs / 32, nt32 = (B + 31) / 32;
+    // S1, S2: the per-tile partials are spread over the threads (one load each, then a fixed-order
+    // tree) instead of every thread walking all of them in batches
+    __shared__ double fin_red[2][4];
     double S1 = 0, S2 = 0;
-    for (int t0 = 0; t0 < nt32; t0 += 8) {
-        float2 pv[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            pv[q] = *reinterpret_cast<const float2*>(&f.S12p[((size_t)u * NT32 + min(t0 + q, nt32 - 1)) * 2]);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { KEEP(pv[q].x); KEEP(pv[q].y); }
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            if (t0 + q < nt32) { S1 += (double)pv[q].x; S2 += (double)pv[q].y; }
+    for (int t = tid; t < nt32; t += nthr) {
+        const float2 pv = *reinterpret_cast<const float2*>(&f.S12p[((size_t)u * NT32 + t) * 2]);
+        S1 += (double)pv.x; S2 += (double)pv.y;
     }
+    S1 = wave_sum_d(S1); S2 = wave_sum_d(S2);
+    if ((tid & 63) == 0) { fin_red[0][tid >> 6] = S1; fin_red[1][tid >> 6] = S2; }
+    __syncthreads();
+    S1 = 0; S2 = 0;
+    for (int w = 0; w < (nthr + 63) / 64; ++w) { S1 += fin_red[0][w]; S2 += fin_red[1][w]; }
     const double sg = f.sig1[u], a = (double)f.g1[u] / sg, mu = f.mug[u];
     for (int i = tid; i < K4; i += nthr) {
         double D = 0;
-        for (int t0 = 0; t0 < nt; t0 += 8) {           // eight partials in flight, fixed-order sum
-            float pv[8];
+        for (int t0 = 0; t0 < nt; t0 += 16) {          // sixteen partials in flight, fixed-order sum
+            float pv[16];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) pv[q] = Dspp[((size_t)u * NT + min(t0 + q, nt - 1)) * K4 + i];
+            for (int q = 0; q < 16; ++q) pv[q] = Dspp[((size_t)u * NT + min(t0 + q, nt - 1)) * K4 + i];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) KEEP(pv[q]);
+            for (int q = 0; q < 16; ++q) KEEP(pv[q]);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) D += (t0 + q < nt) ? (double)pv[q] : 0.0;
+            for (int q = 0; q < 16; ++q) D += (t0 + q < nt) ? (double)pv[q] : 0.0;
         }
         const double val = a * (D - S1 * f.m[i] - (S2 / sg) * (f.Gw[(size_t)u * K4 + i] - mu * f.m[i]));
         f.g_conv_w[(size_t)u * K4 + i] = (u < f.freeze_n) ? 0.f : (float)val;
