@@ -174,18 +174,18 @@ __global__ __launch_bounds__(1024) void logits_kernel(const float* __restrict__ 
     const int b = blockIdx.x * 64 + lane, t = blockIdx.y;
     const float* wr = Wf + (size_t)t * U;
     float acc = 0.f;
-    for (int u0 = wv; u0 < U; u0 += 64) {              // four units (eight loads) in flight
-        float wq[4], oq[4];
+    for (int u0 = wv; u0 < U; u0 += 160) {             // ten units (twenty loads) in flight
+        float wq[10], oq[10];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 10; ++q) {
             const int u = min(u0 + 16 * q, U - 1);
             wq[q] = wr[u];
             oq[q] = o[(size_t)u * Bs + b];
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { KEEP(wq[q]); KEEP(oq[q]); }
+        for (int q = 0; q < 10; ++q) { KEEP(wq[q]); KEEP(oq[q]); }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc = fmaf(u0 + 16 * q < U ? wq[q] : 0.f, oq[q], acc);
+        for (int q = 0; q < 10; ++q) acc = fmaf(u0 + 16 * q < U ? wq[q] : 0.f, oq[q], acc);
     }
     part[wv][lane] = acc;
     __syncthreads();
