@@ -46,22 +46,22 @@ __device__ __forceinline__ void pack_tile(const float* __restrict__ x,
             }
         }
     } else {
-    // four sequences (16 loads) per pass, all issued before any is used (see KEEP in common.h)
-    for (int i0 = q; i0 < 64; i0 += 16) {
-        float v[4][4];
+    // eight sequences (32 loads) per pass, all issued before any is used (see KEEP in common.h)
+    for (int i0 = q; i0 < 64; i0 += 32) {
+        float v[8][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < 8; ++r) {
             const int bc = min(b0 + i0 + 4 * r, B - 1);
             const float* xp = x + (size_t)bc * 4 * L + pc;
 #pragma unroll
             for (int a = 0; a < 4; ++a) v[r][a] = xp[(size_t)a * L];
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < 8; ++r)
 #pragma unroll
             for (int a = 0; a < 4; ++a) KEEP(v[r][a]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < 8; ++r) {
             const int i = i0 + 4 * r, b = b0 + i;
             // padding lanes (b >= B) and positions past the end are 'A': nothing reads their results,
             // and as N they would drag their wavefront through the N corrections of the conv kernels
