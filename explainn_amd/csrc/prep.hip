@@ -224,34 +224,37 @@ __global__ __launch_bounds__(64) void qmom_kernel(
     STAMP(3);
 }
 
-// Large pooled lengths (n > 32): ONE wavefront per (unit, batch chunk) computes every 32x32 tile of
-// the symmetric moment matrix (upper triangle, mirrored on output) from rows staged once in LDS;
-// with a wave per tile pair the same rows were fetched 11 times over.
+// Large pooled lengths (n > 32): one 4-wave block per (unit, batch chunk).  The block stages the rows
+// of a 64-sequence super-tile ONCE in LDS (shifted q values) and its four waves share the NP tile
+// pairs of the symmetric moment matrix (upper triangle, mirrored on output), pair p going to wave
+// p mod 4.  (One wave per chunk doing all pairs needed 15 accumulator tiles = 240 VGPRs and a 36 KB
+// tile per WAVE: one wave per SIMD, 236 us at C4 against a 68 us MFMA roof.)
 template <int NQ>
-__global__ __launch_bounds__(64) void qmom_big_kernel(
+__global__ __launch_bounds__(256) void qmom_big_kernel(
     const float* __restrict__ ext, const float* __restrict__ alpha,
     const float* __restrict__ shift, float* __restrict__ qs0, float* __restrict__ S1p,
     float* __restrict__ S2p, int n, int Bs, int B, int QCH) {
     constexpr int NS = ns_stride(NQ), NWT = (NQ + 31) / 32, NP = NWT * (NWT + 1) / 2;
+    constexpr int NPW = (NP + 3) / 4;                  // tile pairs (accumulators) per wave
     extern __shared__ float qsm[];                     // rows [NWT*32][65], then s0 [NWT*32]
     float* tile = qsm;
     float* s0s = qsm + NWT * 32 * QT_LD;
-    const int u = blockIdx.y, ch = blockIdx.x, lane = threadIdx.x;
+    const int u = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rc = lane & 31, kk = lane >> 5;
     const int per = ((((B + QCH - 1) / QCH) + 63) / 64) * 64;
     const int bbeg = ch * per, bend = min(B, bbeg + per);
     const float a1 = alpha[u], sh1 = shift[u];
     const float* eu = ext + (size_t)u * n * Bs;
-    for (int w = lane; w < NWT * 32; w += 64) {
+    for (int w = tid; w < NWT * 32; w += 256) {
         const float raw = eu[(size_t)min(w, n - 1) * Bs];
         const float sv = (w < n) ? qval(a1, raw, sh1) : 0.f;
         s0s[w] = sv;
         if (ch == 0 && w < NS) qs0[(size_t)u * NS + w] = sv;
     }
     __syncthreads();
-    f32x16q acc[NP];
+    f32x16q acc[NPW];
 #pragma unroll
-    for (int p = 0; p < NP; ++p)
+    for (int p = 0; p < NPW; ++p)
 #pragma unroll
         for (int g = 0; g < 16; ++g) acc[p][g] = 0.f;
     float s1[NWT];
@@ -262,32 +265,71 @@ __global__ __launch_bounds__(64) void qmom_big_kernel(
         const bool live = b < bend;
         const int bcl = live ? b : bbeg;
         __syncthreads();
+        // the four waves stage the row groups of 32 between them (shifted values)
+        for (int t = wave; t < 2 * NWT; t += 4) {       // half row groups: 16 loads in flight per lane
+            float r[16];
 #pragma unroll
-        for (int t = 0; t < NWT; ++t) {                // stage 32 rows at a time (shifted values)
-            float r[32];
+            for (int i = 0; i < 16; ++i) r[i] = eu[(size_t)min(t * 16 + i, n - 1) * Bs + bcl];
 #pragma unroll
-            for (int i = 0; i < 32; ++i) r[i] = eu[(size_t)min(t * 32 + i, n - 1) * Bs + bcl];
+            for (int i = 0; i < 16; ++i) KEEP(r[i]);
 #pragma unroll
-            for (int i = 0; i < 32; ++i) KEEP(r[i]);
-#pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                const int w = t * 32 + i;
+            for (int i = 0; i < 16; ++i) {
+                const int w = t * 16 + i;
                 tile[w * QT_LD + lane] = (live && w < n) ? qval(a1, r[i], sh1) - s0s[w] : 0.f;
             }
         }
         __syncthreads();
-        const int ks = (min(bend - b0, 64) + 1) >> 1;
-        for (int s = 0; s < ks; ++s) {
-            const int col = 2 * s + kk;
-            float a[NWT];
+        if constexpr (NPW <= 2) {
+            // few MFMAs per k-step and wave (n <= 96): the LDS latency would be exposed step by step
+            // always the full 32 k-steps (columns past the chunk end hold zeros), four at a time with the
+            // LDS operands of this wave's pairs read first
+    #pragma unroll 1
+            for (int s0 = 0; s0 < 32; s0 += 4) {
+                float av[NPW][4], bv[NPW][4];
+                int p = 0;
+    #pragma unroll
+                for (int t = 0; t < NWT; ++t)
+    #pragma unroll
+                    for (int t2 = t; t2 < NWT; ++t2, ++p) {
+                        if ((p & 3) != wave) continue;     // wave-uniform
+    #pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int col = 2 * (s0 + q) + kk;
+                            av[p >> 2][q] = tile[(t * 32 + rc) * QT_LD + col];
+                            bv[p >> 2][q] = (t2 == t) ? av[p >> 2][q] : tile[(t2 * 32 + rc) * QT_LD + col];
+                        }
+                    }
+                p = 0;
+    #pragma unroll
+                for (int t = 0; t < NWT; ++t)
+    #pragma unroll
+                    for (int t2 = t; t2 < NWT; ++t2, ++p) {
+                        if ((p & 3) != wave) continue;
+    #pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            if (t2 == t) s1[t] += av[p >> 2][q];   // the diagonal pair's owner also sums the rows
+                            acc[p >> 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p >> 2][q], bv[p >> 2][q],
+                                                                               acc[p >> 2], 0, 0, 0);
+                        }
+                    }
+            }
+    
+        } else {
+            // four MFMAs per k-step keep the pipe busy by themselves (and batching costs occupancy)
+            for (int s = 0; s < 32; ++s) {
+                const int col = 2 * s + kk;
+                int p = 0;
 #pragma unroll
-            for (int t = 0; t < NWT; ++t) { a[t] = tile[(t * 32 + rc) * QT_LD + col]; s1[t] += a[t]; }
-            int p = 0;
+                for (int t = 0; t < NWT; ++t)
 #pragma unroll
-            for (int t = 0; t < NWT; ++t)
-#pragma unroll
-                for (int t2 = t; t2 < NWT; ++t2, ++p)
-                    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], a[t2], acc[p], 0, 0, 0);
+                    for (int t2 = t; t2 < NWT; ++t2, ++p) {
+                        if ((p & 3) != wave) continue;     // wave-uniform
+                        const float av = tile[(t * 32 + rc) * QT_LD + col];
+                        const float bv = (t2 == t) ? av : tile[(t2 * 32 + rc) * QT_LD + col];
+                        if (t2 == t) s1[t] += av;          // the diagonal pair's owner also sums the rows
+                        acc[p >> 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[p >> 2], 0, 0, 0);
+                    }
+            }
         }
     }
     // D[w][w']: lane holds column w' = t2*32+rc, rows w = t*32 + (g&3) + 8(g>>2) + 4kk; mirror it
@@ -297,22 +339,22 @@ __global__ __launch_bounds__(64) void qmom_big_kernel(
     for (int t = 0; t < NWT; ++t)
 #pragma unroll
         for (int t2 = t; t2 < NWT; ++t2, ++p) {
+            if ((p & 3) != wave) continue;
             const int wB = t2 * 32 + rc;
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const int w = t * 32 + (g & 3) + 8 * (g >> 2) + 4 * kk;
                 if (w < NS && wB < NS) {
-                    out[(size_t)w * NS + wB] = acc[p][g];
-                    if (t2 != t) out[(size_t)wB * NS + w] = acc[p][g];
+                    out[(size_t)w * NS + wB] = acc[p >> 2][g];
+                    if (t2 != t) out[(size_t)wB * NS + w] = acc[p >> 2][g];
                 }
             }
+            if (t2 == t) {
+                const float sv = s1[t] + __shfl_xor(s1[t], 32, 64);
+                const int w = t * 32 + rc;
+                if (kk == 0 && w < NS) S1p[((size_t)u * QCH + ch) * NS + w] = sv;
+            }
         }
-#pragma unroll
-    for (int t = 0; t < NWT; ++t) {
-        const float sv = s1[t] + __shfl_xor(s1[t], 32, 64);
-        const int w = t * 32 + rc;
-        if (kk == 0 && w < NS) S1p[((size_t)u * QCH + ch) * NS + w] = sv;
-    }
 }
 
 template <int NQ>
@@ -327,7 +369,7 @@ int launch_qmoments(explainn_ctx* c, int B, hipStream_t s) {
         hipLaunchKernelGGL(qmom_kernel<N>, dim3(c->QCH, c->U, 1), dim3(64), 0, s, c->ext,        \
                            c->alpha, c->shift, c->qs0, c->qS1p, c->qS2p, c->n, c->Bs, B, c->QCH); \
     else                                                                                         \
-        hipLaunchKernelGGL(qmom_big_kernel<N>, dim3(c->QCH, c->U), dim3(64), qmom_big_lds<N>(), s, \
+        hipLaunchKernelGGL(qmom_big_kernel<N>, dim3(c->QCH, c->U), dim3(256), qmom_big_lds<N>(), s, \
                            c->ext, c->alpha, c->shift, c->qs0, c->qS1p, c->qS2p, c->n, c->Bs, B,  \
                            c->QCH)
     NQ_DISPATCH(c->NQ, CALL);
