@@ -99,6 +99,11 @@ class _UnitStack(nn.Sequential):
     def _bind(self, owner):
         self.__dict__["_owner_ref"] = weakref.ref(owner)
 
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state.pop("_owner_ref", None)           # re-bound by the owner's __setstate__/__deepcopy__
+        return state
+
     def _owner(self):
         owner = self.__dict__["_owner_ref"]()
         if owner is None:
@@ -223,6 +228,9 @@ class ExplaiNN(_Model):
         self.dropout_p = DROPOUT_P
         self.validate_input = True
         self.grad_sync = None          # optional callable(flat_grad_tensor): multi-GPU all-reduce
+        # rows [0:n) of the filter gradient are zeroed inside the backward kernel (what the hook of
+        # selene/__init__.py:254-257, 509-515 does to the reference's gradient)
+        self.freeze_top_n_filters = 0
         self._rt = _Runtime()
         if weights_file is not None:
             self.load_weights(weights_file)
@@ -232,13 +240,21 @@ class ExplaiNN(_Model):
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for key, val in self.__dict__.items():
+            if key in ("_slots", "_ps_cache"):        # resolved against THIS object's modules
+                continue
             new.__dict__[key] = _Runtime() if key == "_rt" else copy.deepcopy(val, memo)
         new.linears._bind(new)
         return new
 
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state.pop("_slots", None); state.pop("_ps_cache", None)      # ctypes tables: rebuilt on demand
+        return state
+
     def __setstate__(self, state):
         super().__setstate__(state)
         self.__dict__["_rt"] = _Runtime()
+        self.__dict__.pop("_slots", None); self.__dict__.pop("_ps_cache", None)
         self.linears._bind(self)
 
     # -- plumbing -------------------------------------------------------------------------
@@ -274,8 +290,9 @@ class ExplaiNN(_Model):
         super().__setattr__(name, value)
 
     def _param_slots(self):
-        """(C field, owning module, attribute) for the 23 tensors of explainn_params, resolved once:
-        the per-call lookup is then 23 getattr calls instead of walking named_parameters()."""
+        """(C field, the owning module's parameter/buffer dict, name, dtype) for the 23 tensors of
+        explainn_params, resolved once: the per-call check is then 23 dict lookups instead of
+        walking named_parameters() or going through nn.Module.__getattr__."""
         slots = self.__dict__.get("_slots")
         if slots is None:
             slots = []
@@ -284,22 +301,40 @@ class ExplaiNN(_Model):
                 mod = self
                 for part in path[:-1]:
                     mod = mod[int(part)] if part.isdigit() else getattr(mod, part)
-                slots.append((field, mod, path[-1], torch.int64 if field.endswith("nbt") else torch.float32))
+                store = mod._parameters if path[-1] in mod._parameters else mod._buffers
+                slots.append((field, store, path[-1],
+                              torch.int64 if field.endswith("nbt") else torch.float32))
             self.__dict__["_slots"] = slots
+            self.__dict__.pop("_ps_cache", None)
         return slots
 
     def _params_struct(self, dev):
+        """The explainn_params table (+ the tensors it points into, kept alive with it).  Cached
+        until a parameter object is replaced (train.py:324 re-assigns the filter bank) or its
+        storage moves (`.cuda()`, `.data = ...`); in-place optimiser updates keep it valid."""
+        slots = self._param_slots()
+        cache = self.__dict__.get("_ps_cache")
+        if cache is not None and cache[0] == dev:
+            _, ps, keep, ptrs = cache
+            for (field, store, attr, want), t, ptr in zip(slots, keep, ptrs):
+                cur = store[attr]
+                if cur is not t or cur.data_ptr() != ptr:
+                    break
+            else:
+                return ps, keep
         ps = _lib.Params()
-        keep = []
-        for field, mod, attr, want in self._param_slots():
-            t = getattr(mod, attr)          # looked up per call: callers may re-assign parameters
+        keep, ptrs = [], []
+        for field, store, attr, want in slots:
+            t = store[attr]
             if t.device != dev or t.dtype != want:
                 raise RuntimeError("parameter %s must be %s on %s (is %s on %s)" % (
                     _lib.PARAM_KEYS[field], want, dev, t.dtype, t.device))
             if not t.is_contiguous():
                 raise RuntimeError("parameter %s must be contiguous" % _lib.PARAM_KEYS[field])
             keep.append(t)
-            setattr(ps, field, t.data_ptr())
+            ptrs.append(t.data_ptr())
+            setattr(ps, field, ptrs[-1])
+        self.__dict__["_ps_cache"] = (dev, ps, keep, ptrs)
         return ps, keep
 
     def _prep_input(self, x, dev):
@@ -364,6 +399,7 @@ class ExplaiNN(_Model):
         B = x.shape[0]
         if B == 0:                                   # torch returns an empty (0, T) tensor in eval
             return torch.empty(0, self._options["n_features"], device=dev, dtype=torch.float32)
+        self._rt.token += 1        # eval overwrites the scratch of a train forward still awaiting backward
         ctx = self._context(B, dev)
         ps, keep = self._params_struct(dev)
         logits = torch.empty(B, self._options["n_features"], device=dev, dtype=torch.float32)
@@ -426,7 +462,8 @@ class ExplaiNN(_Model):
         B = dl.shape[0]
         with torch.cuda.device(dev):
             _lib.check(ctx.lib.explainn_backward(ctx.handle, dl.data_ptr(), B, C.byref(ps),
-                                                 C.byref(gs), 0, self._stream(dev)))
+                                                 C.byref(gs), int(self.freeze_top_n_filters),
+                                                 self._stream(dev)))
         if self.grad_sync is not None:
             self.grad_sync(flat)
         return views
@@ -447,6 +484,7 @@ class ExplaiNN(_Model):
         dev = self._device()
         x = self._prep_input(self._first_four_rows(x_rep), dev)
         B = x.shape[0]
+        self._rt.token += 1
         ctx = self._context(B, dev)
         ps, keep = self._params_struct(dev)
         outs = torch.empty(B, self._options["cnn_units"], device=dev, dtype=torch.float32)
@@ -464,6 +502,7 @@ class ExplaiNN(_Model):
         x = self._prep_input(self._first_four_rows(x_rep), dev)
         B = x.shape[0]
         o = self._options
+        self._rt.token += 1
         ctx = self._context(B, dev)
         ps, keep = self._params_struct(dev)
         acts = torch.empty(B, o["cnn_units"], o["sequence_length"] - o["kernel_size"] + 1,
@@ -486,6 +525,7 @@ class ExplaiNN(_Model):
             if select.shape != (B,) or select.device != dev:
                 raise RuntimeError("select must be a (B,) tensor on the model's device")
             select = select.to(torch.uint8).contiguous()
+        self._rt.token += 1
         return dev, x, B, select
 
     def filter_act_max(self, x, unit_max, select=None):

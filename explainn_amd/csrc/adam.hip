@@ -67,11 +67,13 @@ extern "C" int explainn_adam_step(int n_tensors, float* const* params, const flo
     // 1 - beta in double, then rounded: torch passes these weights as doubles to lerp/addcmul
     // (1.f - 0.999f is off by 5e-5 relative)
     const float omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
-    for (int t0 = 0; t0 < n_tensors; t0 += ADAM_MAX_TENSORS) {
+    for (int i = 0; i < n_tensors;) {
+        // one launch per table of up to ADAM_MAX_TENSORS non-empty tensors; `i` carries on from the
+        // last tensor the previous table consumed (empty tensors are skipped without a slot)
         AdamTable tab;
         tab.count = 0;
         tab.first_block[0] = 0;
-        for (int i = t0; i < n_tensors && tab.count < ADAM_MAX_TENSORS; ++i) {
+        for (; i < n_tensors && tab.count < ADAM_MAX_TENSORS; ++i) {
             if (sizes[i] < 0 || (sizes[i] > 0 && (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i]))) {
                 explainn_set_error("adam_step: tensor %d has a null pointer or negative size", i);
                 return EXPLAINN_E_ARG;

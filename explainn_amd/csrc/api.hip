@@ -102,6 +102,10 @@ int check_batch(const explainn_ctx* c, int B) {
     } while (0)
 
 int eval_front(explainn_ctx* c, const float* x, int B, const explainn_params* p, hipStream_t s) {
+    // every eval-mode entry point overwrites scratch a pending backward would read (codes, ext,
+    // idx, z, bits ...): whatever train forward was in flight is gone, and its backward must fail
+    // with E_STATE instead of returning the eval batch's gradients
+    c->fwd_B = 0; c->tail_B = 0;
     TRY(launch_pack(c, x, B, false, s));
     TRY(launch_prep1_tables(c, p, s));
     TRY(launch_prep1(c, p, B, false, s));
@@ -133,7 +137,7 @@ extern "C" int explainn_create(explainn_ctx** out, int cnn_units, int kernel_siz
         explainn_set_error("pooled length n=%d exceeds the largest instantiated kernel (%d)", n, MAX_NQ);
         return EXPLAINN_E_UNSUPPORTED;
     }
-    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipSetDevice(device));                 // (nothing allocated yet)
     explainn_ctx* c = new explainn_ctx();
     memset(c, 0, sizeof(*c));
     c->U = cnn_units; c->k = kernel_size; c->L = sequence_length; c->T = n_features;
@@ -183,15 +187,20 @@ extern "C" int explainn_create(explainn_ctx** out, int cnn_units, int kernel_siz
         delete c;
         return EXPLAINN_E_HIP;
     }
-    HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->seed_ring), SEED_RING * 2 * sizeof(uint32_t), hipHostMallocDefault));
-    int rc = prep_configure(c);
-    if (rc == EXPLAINN_OK) rc = bwd_configure(c);
-    if (rc == EXPLAINN_OK) rc = fc_configure(c);
-    if (rc == EXPLAINN_OK) rc = conv_configure(c);
-    if (rc != EXPLAINN_OK) { (void)hipFree(c->base); delete c; return rc; }
+    // from here on every failure releases what was acquired (explainn_destroy copes with the
+    // members that are still null)
+    int rc = [&]() -> int {
+        HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->seed_ring), SEED_RING * 2 * sizeof(uint32_t), hipHostMallocDefault));
+        TRY(prep_configure(c));
+        TRY(bwd_configure(c));
+        TRY(fc_configure(c));
+        TRY(conv_configure(c));
+        return EXPLAINN_OK;
+    }();
+    if (rc != EXPLAINN_OK) { explainn_destroy(c); return rc; }
     *out = c;
     return EXPLAINN_OK;
 }
@@ -246,6 +255,7 @@ extern "C" int explainn_stage_codes(explainn_ctx* c, const uint8_t* codes, int B
                                     int reverse_complement, void* stream) {
     TRY(check_batch(c, B));
     if (!codes) { explainn_set_error("codes is null"); return EXPLAINN_E_ARG; }
+    c->fwd_B = 0; c->tail_B = 0;       // the packed codes of a pending backward are overwritten
     return launch_pack_codes(c, codes, B, reverse_complement ? 1 : 0, static_cast<hipStream_t>(stream));
 }
 

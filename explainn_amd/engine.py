@@ -18,6 +18,7 @@ class StepEngine:
         self.model = model
         self.dev = model._device()
         self.loss_kind = _lib.LOSS_BCE_WITH_LOGITS if loss == "binary" else _lib.LOSS_MSE
+        self.max_batch = max_batch
         self.ctx = model._context(max_batch, self.dev)
         self.params = list(model.parameters())
         n = sum(p.numel() for p in self.params)
@@ -62,6 +63,13 @@ class StepEngine:
             self.step_no += 1
             seed = self.step_no * 0x9E3779B97F4A7C15 & 0xFFFFFFFFFFFFFFFF
         m = self.model
+        # The context is re-resolved every step: an eval forward with a larger batch in between
+        # (validation batches larger than the train batch, selene/__init__.py:334) makes the model
+        # replace its context by a bigger one, and the one cached here would be closed.
+        if B > self.max_batch:
+            self.max_batch = B
+            self.logits = torch.empty(B, self.logits.shape[1], device=self.dev, dtype=torch.float32)
+        self.ctx = m._context(self.max_batch, self.dev)
         if not (torch.is_tensor(x) and x.dtype == torch.float32):
             x = m._prep_input(x, self.dev)
         stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)

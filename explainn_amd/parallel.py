@@ -37,6 +37,15 @@ def broadcast_parameters(model, src=0):
         dist.broadcast(t.data, src)
 
 
+def average_gradients(flat):
+    """All-reduce (average) of a flat gradient buffer: the `grad_sync` callable of the autograd
+    path (ExplaiNN._launch_backward calls it with the buffer all 14 gradients are views of)."""
+    if world() > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(world())
+    return flat
+
+
 class GradAllReduce:
     """Averages one flat gradient buffer across ranks: a single collective per step.  At C2 the
     buffer is 3.7 MB; RCCL picks its own algorithm."""

@@ -138,7 +138,7 @@ class Trainer(object):
                 getattr(self.criterion, "pos_weight", None) is None)
 
     def _fused_engine(self, batch):
-        if self._engine is None or self._engine.ctx.max_batch < batch:
+        if self._engine is None:
             kind = "binary" if isinstance(self.criterion, torch.nn.BCEWithLogitsLoss) else "linear"
             self._engine = StepEngine(self.model, batch, loss=kind)
             if parallel.world() > 1:
@@ -184,6 +184,11 @@ class Trainer(object):
             if self.model.validate_input and (self.step <= 3 or self.step % 64 == 0):
                 self._check_input_flags()
         else:
+            if parallel.world() > 1 and self.model.grad_sync is None:
+                # the autograd path of a sharded run (weighted / custom criterion): same start and
+                # the same averaged gradients as the fused path, one all-reduce per backward
+                parallel.broadcast_parameters(self.model)
+                self.model.grad_sync = parallel.average_gradients
             predictions = self.model(inputs)
             loss = self.criterion(predictions, targets)
             self.optimizer.zero_grad()

@@ -169,6 +169,16 @@ def test_adam_trajectory_golden(golden):
                 assert knife_edge is not None and knife_edge < step, \
                     "left the reference trajectory at step %d without a ReLU knife-edge" % step
                 following = False
+        if not following:
+            # off the reference trajectory after a knife-edge: a flipped ReLU branch moves one
+            # channel's gradient by one sample's share, and Adam moves a parameter by at most ~lr
+            # per step whatever the gradient's size, so the runs can only part slowly
+            since = step - knife_edge
+            ref = g.group("step%d/sd/" % step)
+            if "linears.0.weight" in ref:
+                d = np.abs(_np(m.state_dict()["linears.0.weight"]) - ref["linears.0.weight"]).max()
+                assert d <= 2 * 0.003 * since, "filters %.3g apart %d steps after the knife-edge" % (d, since)
+            assert abs(loss.item() - g.z["steps/loss"][step - 1]) < 1e-2, step
         margin = min(np.abs(cache["y2"]).min(), np.abs(cache["y3"]).min())
         if margin < 2e-6 and knife_edge is None:
             knife_edge = step
@@ -188,6 +198,10 @@ def test_adam_trajectory_golden(golden):
     (6, 32, 120, 1, 40, 0.03),      # largest instantiated kernel size (two code words per window)
     (5, 2, 40, 2, 33, 0.05),        # smallest kernel size
     (4, 31, 260, 1, 20, 0.02),      # odd kernel size next to the maximum, two staging chunks (n = 32+)
+    # large-n kernels over SEVERAL batch chunks (QCH / ACH > 1, ragged last chunk): qmom_big,
+    # mid_big, passB<140>/<84>, fc_fwd<NQ > 32> -- the code paths configs C4 / C5 run
+    (3, 19, 1000, 2, 300, 0.01),    # n = 140, 3 chunks of 128 (last one 44 sequences)
+    (2, 19, 600, 5, 700, 0.02),     # n = 83, 6 chunks (last one 60)
 ])
 def test_train_step_vs_oracle(U, k, L, T, B, nfrac):
     sd = orc.random_state_dict(U, k, L, T, seed=U + L)
@@ -221,6 +235,120 @@ def test_train_step_vs_oracle(U, k, L, T, B, nfrac):
     sd2 = dict(sd); sd2.update(nb)
     with torch.no_grad():
         _close(_np(m(torch.from_numpy(x).cuda())), orc.forward(sd2, x), what="eval logits")
+
+
+def _oracle_step(sd, x, y, freeze=0, keep=None):
+    ref_logits, cache, nb = orc.forward(sd, x, training=True, dropout_mask=keep, return_cache=True)
+    ref_loss, dl = orc.bce_with_logits(ref_logits, y)
+    return ref_logits, ref_loss, orc.backward(cache, dl, freeze_top_n_filters=freeze), nb
+
+
+def _check_grads(named, ref_grads, what=""):
+    for key, got in named:
+        v = ref_grads[key]
+        if key in ZERO_GRAD:
+            assert np.abs(_np(got)).max() < 1e-6, key
+        else:
+            _close(_np(got).reshape(v.shape), v, tol=2e-4, what="%sgrad %s" % (what, key))
+
+
+@pytest.mark.parametrize("freeze", [1, 3, 5])
+def test_freeze_top_n_filters_vs_oracle(freeze):
+    """The freeze hook (selene/__init__.py:254-257, 509-515: rows [0:n) of the filter gradient are
+    zeroed) as the backward kernel applies it, against `oracle.backward(freeze_top_n_filters=n)`:
+    through explainn_backward (autograd path) and through explainn_train_step (StepEngine)."""
+    from explainn_amd.engine import StepEngine
+    U, k, L, T, B = 5, 19, 61, 2, 40
+    sd = orc.random_state_dict(U, k, L, T, seed=41)
+    x = orc.random_onehot(B, L, seed=42, n_frac=0.02)
+    y = (np.random.default_rng(43).random((B, T)) > 0.5).astype(np.float32)
+    ref_logits, ref_loss, ref_grads, _ = _oracle_step(sd, x, y, freeze=freeze)
+    assert np.abs(ref_grads["linears.0.weight"][:freeze]).max() == 0
+    assert freeze == U or np.abs(ref_grads["linears.0.weight"][freeze:]).max() > 0
+    xt, yt = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    # (a) explainn_forward_train + torch's loss + explainn_backward(freeze)
+    m = _model(sd, U, k, L, T).train()
+    m.dropout_p = 0.0
+    m.freeze_top_n_filters = freeze
+    logits = m(xt)
+    torch.nn.functional.binary_cross_entropy_with_logits(logits, yt).backward()
+    _close(_np(logits), ref_logits, what="logits")
+    _check_grads([(key, p.grad) for key, p in m.named_parameters()], ref_grads, "autograd ")
+    got = _np(m.linears[0].weight.grad)
+    assert np.abs(got[:freeze]).max() == 0, "frozen rows must be exactly zero"
+    # (b) explainn_train_step(freeze)
+    m2 = _model(sd, U, k, L, T).train()
+    m2.dropout_p = 0.0
+    eng = StepEngine(m2, B, loss="binary")
+    logits2, loss2 = eng.step(xt, yt, freeze_top_n_filters=freeze)
+    torch.cuda.synchronize()
+    _close(loss2.item(), ref_loss, tol=1e-5, what="loss")
+    _check_grads([(key, v) for (key, _), v in zip(m2.named_parameters(), eng.views)], ref_grads, "step ")
+    assert np.abs(_np(eng.views[0])[:freeze]).max() == 0
+    assert torch.allclose(eng.views[0], m.linears[0].weight.grad, rtol=1e-4, atol=1e-7)
+
+
+def test_large_context_small_batch_vs_oracle():
+    """A context created for max_batch = 1024 (8 q-moment chunks, 8 passA chunks) used at B = 300:
+    the trailing chunks are empty and must contribute exact zeros."""
+    from explainn_amd.engine import StepEngine
+    U, k, L, T, B = 3, 19, 200, 2, 300
+    sd = orc.random_state_dict(U, k, L, T, seed=51)
+    x = orc.random_onehot(B, L, seed=52, n_frac=0.01)
+    y = (np.random.default_rng(53).random((B, T)) > 0.5).astype(np.float32)
+    ref_logits, ref_loss, ref_grads, nb = _oracle_step(sd, x, y)
+    m = _model(sd, U, k, L, T).train()
+    m.dropout_p = 0.0
+    eng = StepEngine(m, 1024, loss="binary")
+    assert eng.ctx.max_batch == 1024
+    logits, loss = eng.step(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda())
+    torch.cuda.synchronize()
+    _close(_np(logits), ref_logits, what="logits")
+    _close(loss.item(), ref_loss, tol=1e-5, what="loss")
+    _check_grads([(key, v) for (key, _), v in zip(m.named_parameters(), eng.views)], ref_grads)
+    bufs = dict(m.named_buffers())
+    for key, v in nb.items():
+        if "tracked" not in key:
+            _close(_np(bufs[key]), v, what=key)
+
+
+def test_eval_forward_invalidates_a_pending_backward():
+    """`out = model(x)` in train mode, an eval-mode forward of the same batch size (a monitoring
+    pass), then `loss.backward()`: the eval pass has overwritten the scratch the backward reads, so
+    the backward must raise -- the reference's autograd graph would still hold its own
+    activations; silently returning the eval batch's gradients is not an option."""
+    import ctypes
+    from explainn_amd import _lib
+    sd = orc.random_state_dict(3, 5, 40, 1, seed=61)
+    m = _model(sd, 3, 5, 40, 1).train()
+    m.dropout_p = 0.0
+    x = torch.from_numpy(orc.random_onehot(8, 40, seed=62)).cuda()
+    out = m(x)
+    m.eval()
+    with torch.no_grad():
+        m(x)                                           # same B: the batch-size check alone would pass
+    m.train()
+    with pytest.raises(RuntimeError, match="stale forward"):
+        out.sum().backward()
+    # the same at the C ABI: forward_train, forward_eval, backward -> E_STATE
+    dev = m._device()
+    ctx = m._context(8, dev)
+    ps, keep = m._params_struct(dev)
+    logits = torch.empty(8, 1, device=dev)
+    assert ctx.lib.explainn_forward_train(ctx.handle, x.data_ptr(), 8, ctypes.byref(ps), None, 0.0,
+                                          ctypes.c_uint64(0), logits.data_ptr(), None) == _lib.OK
+    assert ctx.lib.explainn_forward_eval(ctx.handle, x.data_ptr(), 8, ctypes.byref(ps),
+                                         logits.data_ptr(), None) == _lib.OK
+    flat = torch.zeros(sum(p.numel() for p in m.parameters()), device=dev)
+    gs = _lib.Grads()
+    off = 0
+    for field, p in zip(_lib.GRAD_FIELDS, m.parameters()):
+        setattr(gs, field, flat[off:].data_ptr()); off += p.numel()
+    dl = torch.ones(8, 1, device=dev)
+    rc = ctx.lib.explainn_backward(ctx.handle, dl.data_ptr(), 8, ctypes.byref(ps), ctypes.byref(gs),
+                                   0, None)
+    torch.cuda.synchronize()
+    assert rc == _lib.E_STATE
 
 
 def test_batch_of_one_in_train_mode_raises():

@@ -31,6 +31,60 @@ def _batch(seed=1, n_frac=0.002):
     return torch.from_numpy(orc.random_onehot(B, L, seed=seed, n_frac=n_frac)).cuda()
 
 
+KNIFE = 5e-6     # |pre-activation| below this: fp32 and fp64 may legitimately disagree on its sign
+
+
+def _knife_masks(cache, U_):
+    """Which gradient entries a ReLU sign disagreement between two correct implementations could
+    move.  A flip of y2[b,u,r] changes d2 there, i.e. rows (u,r) of linears.{6,7}.* by one sample's
+    share (~1/B of the row) and unit u's filter / BatchNorm1 gradients by ~1/(100 B); a flip of
+    y3[b,u] changes d3 there, i.e. everything of unit u by ~1/B.  Returns (channel mask (U,100),
+    unit mask (U,)) of the entries that may NOT be compared tightly."""
+    Bc = cache["y2"].shape[0]
+    ch = np.abs(cache["y2"].reshape(Bc, U_, 100)).min(axis=0) < KNIFE
+    un = (np.abs(cache["y3"]).min(axis=0) < KNIFE) | ch.any(axis=1)
+    return ch, un
+
+
+def _compare_masked(named_grads, ref, cache, U_, tight=2e-4, loose=1e-2):
+    """Every gradient against the oracle: `tight` x max|ref| everywhere except the knife-edge
+    channels / units of _knife_masks, which only have to stay within `loose`."""
+    ch, un = _knife_masks(cache, U_)
+    # the masks must stay a small exception: under 2 % of the channels, and enough clean units left
+    # for the tight comparison to mean something (an indexing bug hits every unit alike)
+    assert ch.mean() < 0.02 and (~un).sum() >= max(2, U_ // 8), (ch.mean(), un.mean())
+    report = {}
+    for name, g in named_grads:
+        r = ref[name].reshape(tuple(g.shape))
+        got = g.detach().cpu().numpy()
+        if name in ("linears.0.bias", "linears.6.bias", "linears.10.bias"):
+            assert np.abs(got).max() < 1e-6, name           # identically zero (SURVEY.md 7.2)
+            continue
+        if name == "linears.1.bias":
+            continue                                       # near-null direction (SURVEY.md 7.2)
+        scale = np.abs(r).max()
+        err = np.abs(got - r)
+        if name.startswith(("linears.6.", "linears.7.")):
+            rows = ch.reshape(-1)                           # channel index u*100 + r
+        elif name.startswith(("linears.0.", "linears.1.", "linears.10.", "linears.11.")):
+            rows = un
+        else:
+            rows = np.zeros(err.shape[0] if name != "final.weight" else 0, dtype=bool)
+        if name == "final.weight":                          # (T, U): columns are units; o ~ 0 at a knife-edge
+            masked, clean = err[:, un], err[:, ~un]
+        elif rows.size:
+            masked, clean = err[rows], err[~rows]
+        else:
+            masked, clean = err[:0], err
+        report[name] = (clean.max() / scale if clean.size else 0.0, masked.max() / scale if masked.size else 0.0)
+        assert clean.size == 0 or clean.max() <= tight * scale, (name, "clean", report[name])
+        assert masked.size == 0 or masked.max() <= loose * scale, (name, "knife-edge", report[name])
+    print("masked comparison: %.2f%% channels, %d/%d units masked; worst clean %.2e, worst masked %.2e" % (
+        100 * ch.mean(), int(un.sum()), U_, max(v[0] for v in report.values()),
+        max(v[1] for v in report.values())))
+    return report
+
+
 def _grads(m, x, y, scale=1.0):
     m.train()
     m.zero_grad()
@@ -52,15 +106,14 @@ def test_c2_batch_permutation_equivariance():
     perm = torch.randperm(B, generator=torch.Generator().manual_seed(4)).cuda()
     lg2, g2 = _grads(m, x[perm], y[perm])
     assert (lg1[perm] - lg2).abs().max().item() < 1e-4
-    for (name, _), a, b in zip(m.named_parameters(), g1, g2):
-        scale = max(1e-6, a.abs().max().item())
-        # Among the 30.7 M ReLU pre-activations of a C2 batch a few dozen lie within 1e-6 of zero
-        # (25 for this input); a different lane/tile assignment changes fp32 summation order in the
-        # batch statistics, flips the sign of some of them, and each flip moves one channel's
-        # gradient by one sample's share.  Tensors downstream of that ReLU in the backward pass get
-        # 1e-2 of their max; the ones upstream of it are compared tightly.
-        tight = name.startswith(("final", "linears.11", "linears.10"))
-        assert (a - b).abs().max().item() <= (2e-4 if tight else 1e-2) * scale + 1e-7, name
+    # Among the 30.7 M ReLU pre-activations of a C2 batch some lie within rounding of zero; a
+    # different lane/tile assignment changes fp32 summation order in the batch statistics and may
+    # flip such a sign.  The oracle's forward says which channels / units those are; everything
+    # else must agree to 2e-4 of the tensor's max.
+    sd_np = {k: v.cpu().numpy() for k, v in sd0.items()}
+    _, cache, _ = orc.forward(sd_np, x.cpu().numpy(), training=True, return_cache=True, dtype=np.float64)
+    ref = {name: a.cpu().numpy() for (name, _), a in zip(m.named_parameters(), g1)}
+    _compare_masked([(name, b) for (name, _), b in zip(m.named_parameters(), g2)], ref, cache, U)
 
 
 def test_c2_backward_is_linear_in_the_loss_gradient():
@@ -161,8 +214,8 @@ def test_empty_batch_follows_torch():
 
 def test_c2_full_size_against_fp64_oracle():
     """Train-mode logits and all gradients at the full C2 size against the numpy oracle in fp64
-    (a few seconds of host time).  Logits within 1e-4; gradients upstream of the hidden ReLU within
-    2e-4 of the tensor's max; those downstream within 1e-2 (ReLU knife-edges, see above)."""
+    (a few seconds of host time).  Logits within 1e-4; every gradient within 2e-4 of the tensor's
+    max, except the rows the oracle itself marks as ReLU knife-edges (_knife_masks)."""
     m = _c2_model(seed=3)
     x = _batch(seed=11)
     y = (torch.rand(B, T, generator=torch.Generator().manual_seed(12)) > 0.5).float().cuda()
@@ -173,17 +226,7 @@ def test_c2_full_size_against_fp64_oracle():
     _, dl = orc.bce_with_logits(ref_logits, y.cpu().numpy().astype(np.float64))
     ref = orc.backward(cache, dl)
     assert np.abs(logits.cpu().numpy() - ref_logits).max() < 1e-4
-    for (name, _), g in zip(m.named_parameters(), grads):
-        r = ref[name].reshape(tuple(g.shape))
-        if name in ("linears.0.bias", "linears.6.bias", "linears.10.bias"):
-            assert g.abs().max().item() < 1e-6, name       # identically zero
-            continue
-        if name == "linears.1.bias":
-            continue                                       # near-null direction
-        scale = np.abs(r).max()
-        tight = name.startswith(("final", "linears.11", "linears.10"))
-        err = np.abs(g.cpu().numpy() - r).max()
-        assert err <= (2e-4 if tight else 1e-2) * scale, (name, err, scale)
+    _compare_masked([(name, g) for (name, _), g in zip(m.named_parameters(), grads)], ref, cache, U)
     bufs = dict(m.named_buffers())
     for key, v in nb.items():
         if "tracked" not in key:
@@ -213,17 +256,7 @@ def test_c3_batch_and_tasks_against_fp64_oracle():
     ref = orc.backward(cache, dl)
     assert np.abs(logits.cpu().numpy() - ref_logits).max() < 1e-4
     assert abs(loss.item() - ref_loss) < 1e-5
-    for (name, _), g in zip(m.named_parameters(), eng.views):
-        r = ref[name].reshape(tuple(g.shape))
-        if name in ("linears.0.bias", "linears.6.bias", "linears.10.bias"):
-            assert g.abs().max().item() < 1e-6, name
-            continue
-        if name == "linears.1.bias":
-            continue
-        scale = np.abs(r).max()
-        tight = name.startswith(("final", "linears.11", "linears.10"))
-        err = np.abs(g.cpu().numpy() - r).max()
-        assert err <= (2e-4 if tight else 1e-2) * scale, (name, err, scale)
+    _compare_masked([(name, g) for (name, _), g in zip(m.named_parameters(), eng.views)], ref, cache, U3)
     # the autograd path (torch's own BCE, explainn_backward) lands on the same gradients
     m.zero_grad()
     out = m(x)
@@ -231,3 +264,108 @@ def test_c3_batch_and_tasks_against_fp64_oracle():
     assert torch.allclose(out, logits, atol=0, rtol=0)
     for (name, p), g in zip(m.named_parameters(), eng.views):
         assert torch.allclose(p.grad, g, rtol=1e-4, atol=1e-6 * float(g.abs().max()) + 1e-12), name
+
+
+def _shard_case(Uc, Lc, Tc, Bc, seed):
+    """One per-GPU shard of configs C4 / C5 (BASELINE.json configs[3], [4]: B = 1024 per GPU) at a
+    handful of units, through explainn_train_step, against the fp64 oracle."""
+    from explainn_amd import ExplaiNN
+    from explainn_amd.engine import StepEngine
+    torch.manual_seed(seed)
+    m = ExplaiNN(Uc, K, Lc, Tc).cuda().train()
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(seed + 1)
+        for i in (1, 7, 11):
+            bn = m.linears[i]
+            bn.weight.copy_((0.6 + 0.8 * torch.rand(bn.weight.shape, generator=g)).cuda())
+            bn.bias.copy_((0.2 * torch.randn(bn.bias.shape, generator=g)).cuda())
+        m.linears[1].weight[::3] *= -1
+    m.dropout_p = 0.0
+    x = torch.from_numpy(orc.random_onehot(Bc, Lc, seed=seed + 2, n_frac=0.002)).cuda()
+    y = (torch.rand(Bc, Tc, generator=torch.Generator().manual_seed(seed + 3)) > 0.5).float().cuda()
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    eng = StepEngine(m, Bc, loss="binary")
+    logits, loss = eng.step(x, y)
+    torch.cuda.synchronize()
+    ref_logits, cache, nb = orc.forward(sd, x.cpu().numpy(), training=True, return_cache=True,
+                                        dtype=np.float64)
+    ref_loss, dl = orc.bce_with_logits(ref_logits, y.cpu().numpy().astype(np.float64))
+    ref = orc.backward(cache, dl)
+    assert np.abs(logits.cpu().numpy() - ref_logits).max() < 1e-4
+    assert abs(loss.item() - ref_loss) < 1e-5
+    rep = _compare_masked([(name, g) for (name, _), g in zip(m.named_parameters(), eng.views)],
+                          ref, cache, Uc)
+    bufs = dict(m.named_buffers())
+    for key, v in nb.items():
+        if "tracked" not in key:
+            assert np.abs(bufs[key].cpu().numpy() - v).max() < 1e-4 * max(1.0, np.abs(v).max()), key
+    return rep
+
+
+def test_c4_shard_shape_against_fp64_oracle():
+    """Config C4's per-GPU shard: L = 1000 (n = 140), T = 50, B = 1024 -- qmom_big / mid_big /
+    passB<140> / fc_fwd<140> with all 8 q-moment chunks and 8 passA chunks live."""
+    _shard_case(8, 1000, 50, 1024, seed=31)
+
+
+def test_c5_shard_shape_against_fp64_oracle():
+    """Config C5's per-GPU shard: L = 600 (n = 83 -> bucket 84), T = 164, B = 1024."""
+    _shard_case(8, 600, 164, 1024, seed=41)
+
+
+def test_c5_unit_count_determinism_and_unit_permutation():
+    """U = 2000 (config C5) at B = 128: 2.7 GB-class scratch indexing (size_t offsets into ext /
+    dy / partials) and a grid of 2000 units.  Two identical steps are bitwise identical, and
+    permuting the units (every per-unit parameter row together with its column of final.weight)
+    permutes every per-unit gradient the same way and leaves the logits unchanged to 1e-4."""
+    from explainn_amd import ExplaiNN
+    from explainn_amd.engine import StepEngine
+    Uc, Lc, Tc, Bc = 2000, 600, 164, 128
+    torch.manual_seed(51)
+    m = ExplaiNN(Uc, K, Lc, Tc).cuda().train()
+    m.dropout_p = 0.0
+    x = torch.from_numpy(orc.random_onehot(Bc, Lc, seed=52, n_frac=0.002)).cuda()
+    y = (torch.rand(Bc, Tc, generator=torch.Generator().manual_seed(53)) > 0.5).float().cuda()
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    eng = StepEngine(m, Bc, loss="binary")
+    lg1, _ = eng.step(x, y)
+    lg1 = lg1.clone(); g1 = [v.clone() for v in eng.views]
+    m.load_state_dict(sd0)
+    lg2, _ = eng.step(x, y)
+    assert torch.equal(lg1, lg2)
+    for (name, _), a, b in zip(m.named_parameters(), g1, eng.views):
+        assert torch.equal(a, b), name
+        assert torch.isfinite(a).all(), name
+    # unit permutation
+    perm = torch.randperm(Uc, generator=torch.Generator().manual_seed(54)).cuda()
+    n = m._n
+    sdp = {}
+    for key, v in sd0.items():
+        if key.startswith("linears.6.") or key.startswith("linears.7."):
+            if v.dim() == 0:
+                sdp[key] = v.clone()
+            else:
+                sdp[key] = v.reshape((Uc, 100) + tuple(v.shape[1:]))[perm].reshape(v.shape).clone()
+        elif key == "final.weight":
+            sdp[key] = v[:, perm].clone()
+        elif key == "final.bias" or v.dim() == 0:
+            sdp[key] = v.clone()
+        else:
+            sdp[key] = v[perm].clone()
+    m.load_state_dict(sdp)
+    lg3, _ = eng.step(x, y)
+    assert (lg1 - lg3).abs().max().item() < 1e-4
+    for (name, _), a, b in zip(m.named_parameters(), g1, eng.views):
+        if name.startswith(("linears.6.", "linears.7.")):
+            ap = a.reshape((Uc, 100) + tuple(a.shape[1:]))[perm].reshape(a.shape)
+        elif name == "final.weight":
+            ap = a[:, perm]
+        elif name == "final.bias":
+            ap = a
+        else:
+            ap = a[perm]
+        scale = max(1e-6, a.abs().max().item())
+        # units are independent until `final`: a permuted unit sees exactly the same inputs, so its
+        # gradients are bitwise those of the unpermuted run; only what sums over units (the logits,
+        # hence dlogits and everything scaled by them) moves by rounding
+        assert (ap - b).abs().max().item() <= 2e-4 * scale + 1e-9, name

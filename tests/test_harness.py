@@ -176,3 +176,110 @@ def test_batched_loader_yields_what_the_stock_loader_yields():
         for (gx, gy), (wx, wy) in zip(got, want):
             assert torch.equal(gx, wx) and torch.equal(gy, wy)
     assert ours.batch_size == 11                  # 37 % 12 == 1: shrunk so that no batch has one sample
+
+
+# ---- transfer learning / filter freezing (train.py:316-324, selene/__init__.py:254-257) ----------
+def _transfer_fixture():
+    z = np.load(os.path.join(GOLDEN, "transfer.npz"), allow_pickle=False)
+    U, k, L, T, B, N = [int(v) for v in z["cfg"]]
+    codes = z["codes"]
+    x = np.zeros((codes.shape[0], 4, L), dtype=np.float32)
+    for a in range(4):
+        x[:, a, :] = codes == a
+    sd = {key[3:]: torch.from_numpy(np.array(z[key])) for key in z.files if key.startswith("sd/")}
+    return z, (U, k, L, T, B, N), torch.from_numpy(x), torch.from_numpy(z["y"]), sd
+
+
+def test_transfer_learning_needs_a_filter_per_unit():
+    """Fewer pre-trained filters than units: the reference indexes filter_weights[i] for every unit
+    (train.py:320) and raises IndexError; so does the drop-in (before any device work)."""
+    from explainn_amd.train import _train
+    z, (U, k, L, T, B, N), x, y, sd = _transfer_fixture()
+    assert str(z["short_raises"]) == "IndexError"
+    fw = [torch.from_numpy(w) for w in z["filter_weights"][:U - 1]]
+    with pytest.raises(IndexError):
+        _train(L, T, {}, "binary", 4, cnn_units=U, kernel_size=k, filter_weights=fw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("freeze", [False, True])
+def test_transfer_learning_matches_reference(tmp_path, monkeypatch, freeze):
+    """`_train(filter_weights=..., freeze=...)` against the run of the reference's own `_train`
+    (tests/golden/transfer.npz): the reference builds Adam before it re-assigns
+    `linears[0].weight`, so the given filters never move -- frozen or not -- while every other
+    parameter trains; train.txt / validation loss / final parameters match."""
+    from torch.utils.data import DataLoader, TensorDataset
+    import explainn_amd.train as tr
+    z, (U, k, L, T, B, N), x, y, sd = _transfer_fixture()
+    tag = "freeze" if freeze else "plain"
+    built = {}
+
+    def factory(*a, **kw):
+        m = tr_ExplaiNN(*a, **kw)
+        m.load_state_dict(sd)
+        m.dropout_p = 0.0
+        built["model"] = m
+        return m
+    tr_ExplaiNN = tr.ExplaiNN
+    monkeypatch.setattr(tr, "ExplaiNN", factory)
+    loaders = {"train": DataLoader(TensorDataset(x[:N], y[:N]), B, shuffle=False),
+               "validation": DataLoader(TensorDataset(x[N:], y[N:]), B, shuffle=False)}
+    fw = [torch.from_numpy(w) for w in z["filter_weights"]]
+    trainer = tr._train(L, T, loaders, "binary", N // B, cnn_units=U, kernel_size=k, lr=0.003,
+                        max_epochs=2, patience=10, cpu_threads=1, output_dir=str(tmp_path),
+                        filter_weights=fw, freeze=freeze)
+    assert trainer.freeze_top_n_filters == (U if freeze else 0)
+    m = built["model"]
+    filters = m.linears[0].weight.detach().cpu().numpy()
+    assert np.array_equal(filters, z["filter_weights"][:U]), "the filter bank must not move"
+    assert np.array_equal(filters, z[tag + "/final/linears.0.weight"])
+    train_txt = np.array([float(v) for v in open(tmp_path / "train.txt").read().split()[1:]])
+    assert np.abs(train_txt - z[tag + "/train_txt"]).max() < 1e-4, (train_txt, z[tag + "/train_txt"])
+    lines = open(tmp_path / "validation.txt").read().strip().split("\n")[1:]
+    val = np.array([float(ln.split("\t")[0]) for ln in lines])
+    assert np.abs(val - z[tag + "/val_loss"]).max() < 5e-4
+    final = {key: v.detach().cpu().numpy() for key, v in m.state_dict().items()}
+    for key in ("final.weight", "final.bias", "linears.1.weight", "linears.7.weight",
+                "linears.10.weight", "linears.11.weight", "linears.11.bias", "linears.6.weight"):
+        ref = z[tag + "/final/" + key]
+        assert np.abs(final[key] - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max()), key
+        assert np.abs(final[key] - sd[key].numpy()).max() > 1e-4, key + " must have trained"
+
+
+@pytest.mark.gpu
+def test_validation_batches_larger_than_train_batches(tmp_path):
+    """101 training sequences at batch_size 100: train.py:297-302 shrinks only the TRAIN loader (to
+    99), so validation batches (100) are larger than any train batch.  The eval forward then makes
+    the model replace its device context by a larger one; the fused step must pick the new context
+    up instead of stepping on the closed one.  The run equals the autograd-path run."""
+    from explainn_amd import ExplaiNN, get_loss, get_metrics, get_optimizer
+    from explainn_amd.selene import Trainer
+    from explainn_amd.train import _get_data_loader
+    rng = np.random.default_rng(3)
+    L, U, k = 40, 4, 9
+    codes = rng.integers(0, 4, size=(221, L))
+    x = np.zeros((221, 4, L), dtype=np.float32)
+    for a in range(4):
+        x[:, a, :] = codes == a
+    y = (rng.random((221, 1)) > 0.5).astype(np.float32)
+    results = []
+    for fused in (True, False):
+        torch.manual_seed(1)
+        model = ExplaiNN(U, k, L, 1)
+        model.dropout_p = 0.0
+        loaders = {"train": _get_data_loader(x[:101], y[:101], 100, shuffle=False),
+                   "validation": _get_data_loader(x[101:], y[101:], 100, shuffle=False)}
+        assert loaders["train"].batch_size == 99 and loaders["validation"].batch_size == 100
+        crit = get_loss("binary") if fused else torch.nn.BCEWithLogitsLoss(pos_weight=torch.ones(1))
+        out = tmp_path / ("fused" if fused else "autograd")
+        tr = Trainer(model, loaders, crit, get_metrics("binary"),
+                     get_optimizer(model.parameters(), 0.003), max_steps=6, patience=100,
+                     report_stats_every_n_steps=2, output_dir=str(out), use_cuda=True,
+                     logging_verbosity=0)
+        assert tr._fused_step_available() == fused
+        tr.train_and_validate()
+        results.append((np.loadtxt(out / "train.txt", skiprows=1),
+                        np.loadtxt(out / "validation.txt", skiprows=1, usecols=0)))
+    assert results[0][0].shape == (3,)
+    assert np.abs(results[0][0] - results[1][0]).max() < 1e-5
+    assert np.abs(results[0][1] - results[1][1]).max() < 1e-4

@@ -234,6 +234,89 @@ def make_trainer_case():
     print("trainer_run", out["train_txt"], out["val_txt"])
 
 
+def make_transfer_case():
+    """Transfer learning / filter freezing exactly as the reference drives it: the reference's own
+    `train._train` (train.py:304-342) is imported and called with `filter_weights` (and `freeze`
+    on / off).  Only two things are patched, both outside the code under test: click_option_group
+    (absent here, used only by the CLI decorators) is stubbed, and the `ExplaiNN` name inside the
+    reference's train module is wrapped so that the model it builds has Dropout p = 0 (the run must
+    be deterministic) and so that the model object can be read back after training (`_train`
+    returns nothing).  Loaders are unshuffled.
+
+    What the reference does (and what the fixture pins): the optimiser is built BEFORE
+    `linears[0].weight` is re-assigned to a new nn.Parameter (train.py:314 vs :324), so Adam keeps
+    the stale Parameter, which never receives a gradient again -- the filter bank stays exactly at
+    `filter_weights` whether `freeze` is set or not; every other parameter trains normally."""
+    import tempfile
+    import types as _types
+    cog = _types.ModuleType("click_option_group")
+
+    class _OptGroup:
+        @staticmethod
+        def group(*a, **k):
+            return lambda f: f
+
+        @staticmethod
+        def option(*a, **k):
+            return lambda f: f
+    cog.optgroup = _OptGroup
+    sys.modules["click_option_group"] = cog
+    import train as ref_train                                   # the reference's train.py
+    from torch.utils.data import DataLoader, TensorDataset
+    U, k, L, T, B, N = 6, 9, 50, 1, 16, 64
+    codes = make_codes(N + 32, L, 52, 0.01)
+    g = torch.Generator().manual_seed(53)
+    y = (torch.rand(N + 32, T, generator=g) > 0.5).float()
+    x = torch.from_numpy(codes_to_onehot(codes))
+    fw = [0.5 * torch.randn(4, k, generator=g) for _ in range(U + 2)]       # two more than needed
+    out = dict(cfg=np.array([U, k, L, T, B, N], dtype=np.int64), codes=codes, y=y.numpy(),
+               filter_weights=torch.stack(fw).numpy())
+    steps_per_epoch = N // B
+    for tag, freeze in (("plain", False), ("freeze", True)):
+        loaders = {"train": DataLoader(TensorDataset(x[:N], y[:N]), B, shuffle=False),
+                   "validation": DataLoader(TensorDataset(x[N:], y[N:]), B, shuffle=False)}
+        built = {}
+
+        def _explainn_p0(*a, **kw):
+            m = ExplaiNN(*a, **kw)
+            m.linears[9].p = 0.0
+            built["model"] = m
+            built["sd0"] = {k_: v.clone() for k_, v in m.state_dict().items()}
+            return m
+        ref_train.ExplaiNN = _explainn_p0
+        torch.manual_seed(51)
+        with tempfile.TemporaryDirectory() as d:
+            ref_train._train(L, T, loaders, "binary", steps_per_epoch, cnn_units=U, kernel_size=k,
+                             lr=0.003, max_epochs=2, patience=10, cpu_threads=1, output_dir=d,
+                             filter_weights=fw, freeze=freeze)
+            train_txt = open(os.path.join(d, "train.txt")).read().split()
+            val_lines = open(os.path.join(d, "validation.txt")).read().strip().split("\n")
+        m = built["model"]
+        if tag == "plain":
+            out.update({"sd/" + k_: v.numpy().copy() for k_, v in built["sd0"].items()})
+        out[tag + "/train_txt"] = np.array([float(v) for v in train_txt[1:]])
+        out[tag + "/val_loss"] = np.array([float(ln.split("\t")[0]) for ln in val_lines[1:]])
+        for k_, v in m.state_dict().items():
+            if "running" in k_ or "tracked" in k_:
+                continue
+            out[tag + "/final/" + k_] = v.detach().numpy().copy()
+        moved = float((m.linears[0].weight.detach() - torch.stack(fw[:U])).abs().max())
+        print("transfer/%s: filters moved %.3g, final.weight moved %.3g" % (
+            tag, moved, float((m.final.weight.detach() - built["sd0"]["final.weight"]).abs().max())))
+        # fewer filters than units is an IndexError in the reference (train.py:320)
+    try:
+        ref_train._train(L, T, loaders, "binary", steps_per_epoch, cnn_units=U, kernel_size=k,
+                         max_epochs=1, output_dir=tempfile.mkdtemp(), filter_weights=fw[:U - 1])
+        out["short_raises"] = np.array("none")
+    except Exception as e:                                       # noqa: BLE001
+        out["short_raises"] = np.array(type(e).__name__)
+    import logging
+    for nm in ("selene", "train", "validation"):
+        logging.getLogger(nm).handlers.clear()
+    np.savez_compressed(os.path.join(OUT, "transfer.npz"), **out)
+    print("transfer", out["plain/train_txt"], out["freeze/train_txt"], out["short_raises"])
+
+
 def make_encoding_case():
     seqs = ["ACGT", "acgtn", "NNACGTRYACGT", "TTTTGGGGCCCCAAAA", "A"]
     out = {}
@@ -339,6 +422,9 @@ if __name__ == "__main__":
     make_encoding_case()
     if len(sys.argv) > 1 and sys.argv[1] == "trainer":
         make_trainer_case()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "transfer":
+        make_transfer_case()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "pwm":
         make_pwm_case()
