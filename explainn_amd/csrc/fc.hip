@@ -1,41 +1,46 @@
 // The per-unit two-layer FC (architectures/__init__.py:84-100) and its backward on the exact-fp32
-// matrix cores: v_mfma_f32_32x32x2_f32 is bit-for-bit a k-ordered fmaf chain and runs at the fp32
+// matrix cores: v_mfma_f32_16x16x4_f32 is bit-for-bit a k-ordered fmaf chain and runs at the fp32
 // vector rate, but takes both operands from VGPRs -- no scalar/LDS broadcast stream to feed.
 // FC1 is the one dense contraction on this path: per unit (B x n).(n x 100).
 //
-// Fragment convention (cdna_hip_programming.md section 3), lane l, rc = l&31, kk = l>>5:
-//   D[i][j] = sum_k A[i][k] B[k][j] + C[i][j];  A operand = A[rc][2s+kk],  B operand = B[2s+kk][rc]
-//   C/D register g of lane l holds D[(g&3) + 8*(g>>2) + 4*kk][rc].
+// 16x16x4 tiles (round 2; round 1 used 32x32x2): the hidden width 100 pads to 7 x 16 = 112 instead of
+// 4 x 32 = 128, the accumulator tile is 4 registers instead of 16 (all 7 channel tiles of a sequence
+// tile stay live, so the operand of a k-step is built once and used 7 times), and the dependent
+// latency is 40 cycles against an issue interval of 32: two independent chains saturate the pipe.
+//
+// Fragment convention (cdna_hip_programming.md section 3), lane l, c = l&15, g = l>>4:
+//   D[i][j] = sum_k A[i][k] B[k][j] + C[i][j];  A operand = A[c][4s+g],  B operand = B[4s+g][c]
+//   C/D register i of lane l holds D[4g + i][c].
 //
 //   fc_fwd   D[r][b] = sum_w A2[r][w] q[b][w] + sh2[r].  A = folded FC1 weights (fragments staged
-//            in LDS once per workgroup), B = q of 32 sequences (registers).  A lane ends up with 16
-//            hidden channels of ITS sequence per r-tile: ReLU, dropout, the FC2 dot product
-//            z += V2[r]*a and the 100 "relu'>0 and kept" bits are all lane-local; the two lane
-//            halves are merged with one cross-half shuffle.  Nothing of size (B,100U) is stored.
+//            in LDS once per workgroup), B = q of 16 sequences (registers).  A lane ends up with 4
+//            hidden channels of ITS sequence per channel tile: ReLU, dropout, the FC2 dot product
+//            z += V2[r]*a and the "relu'>0 and kept" bits are lane-local; the four lane groups of a
+//            sequence are merged with two cross-group shuffles.  Nothing of size (B,100U) is stored.
 //   passA    D[r][w] = sum_b e[b][r] q[b][w],  e = dz[b]*bit[b][r] built on the fly from the bit
-//            words (A operand), q rows from the sequence-major copy (B operand).
+//            words (A operand), q rows from a wave-private LDS tile (B operand); K = sequences.
 //   passB    D[w][b] = sum_r T[r][w] e[b][r] - sum_v M[v][w] q[b][v] - k0'[w]; then dy = dq*q and
-//            the two BatchNorm1-backward sums.  A = T and M fragments in LDS.
-//   qmom     (prep.hip) the q second-moment matrix, same instruction.
+//            the two BatchNorm1-backward sums.  A = T and M fragments in LDS.  The k order of the
+//            M.q product is chosen so that a lane's q operands ARE the q values of its D rows.
+//   qmom     (prep.hip) the q second-moment matrix.
 //
-// Template parameter NQ >= n (bucketed pooled length); hidden width 100 is padded to 4 tiles of 32.
+// Template parameter NQ >= n (bucketed pooled length).
 #include "common.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
 
-#define FC_RT 4                      // r-tiles of 32 covering the 100 hidden channels
-#define FC_BTW 2                     // 32-sequence tiles per wavefront in fc_fwd
-#define PB_BTW 2                     // ... in passB
+#define FC_BTW 4                     // 16-sequence tiles per wavefront in fc_fwd
+#define PB_BTW 4                     // ... in passB
 
 // MODE: 0 eval, 1 train without dropout, 2 train + counter-based generator, 3 train + keep-mask
 template <int NQ, int MODE>
-__global__ __launch_bounds__(256, (NQ <= 32 ? 5 : 1)) void fc_fwd_kernel(
+__global__ __launch_bounds__(256) void fc_fwd_kernel(
     const float* __restrict__ ext, const float* __restrict__ alpha,
     const float* __restrict__ shift, const float* __restrict__ A2f, const float* __restrict__ sh2,
     const float* __restrict__ V2, uint4* __restrict__ bits, float* __restrict__ zout,
@@ -43,77 +48,105 @@ __global__ __launch_bounds__(256, (NQ <= 32 ? 5 : 1)) void fc_fwd_kernel(
     uint32_t seed_hi, const float* __restrict__ c2, const float* __restrict__ g3,
     const float* __restrict__ b3, const float* __restrict__ rm3, const float* __restrict__ rv3,
     float* __restrict__ oout, int n, int Bs, int B, int U, const uint32_t* __restrict__ seed_dev) {
-    constexpr int NS = ns_stride(NQ), NKS = (NQ + 1) / 2;
+    constexpr int NK4 = fc_nk4(NQ), NK4Q = fc_nk4q(NQ);
     constexpr bool TRAIN = MODE != 0;
     // a captured step (hipGraph) reads its dropout seed from device memory, so that replays can
     // use a new one; direct launches pass it by value
     if (MODE == 2 && seed_dev) { seed_lo = seed_dev[0]; seed_hi = seed_dev[1]; }
-    __shared__ __attribute__((aligned(16))) float Af[FC_RT * NKS * 64];
-    __shared__ __attribute__((aligned(16))) float sh2s[128];
-    __shared__ __attribute__((aligned(16))) float v2s[128];
+    extern __shared__ __attribute__((aligned(16))) float fsm[];
+    float4* Af = reinterpret_cast<float4*>(fsm);            // [FC_MT][NK4Q][64] float4 (4 k-steps each)
+    float* sh2s = fsm + FC_MT * NK4Q * 64 * 4;               // [112]
+    float* v2s = sh2s + FC_MT * 16;                          // [112]
     const int u = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rc = lane & 31, kk = lane >> 5;
+    const int c = lane & 15, g = lane >> 4;
+    const float* __restrict__ eu = ext + (size_t)u * n * Bs;
+    const int bt0 = (blockIdx.x * 4 + wave) * FC_BTW;
     STAMP(0);
-    // stage the A fragments (prep2 wrote them in fragment order):
-    // Af[(t*NKS+s)*64 + l] = A2[32t + (l&31)][2s + (l>>5)]
+    // the first tile's raw pooled extremes are requested before the weight fragments are staged:
+    // one memory round trip covers both
+    float raw[NK4];
     {
-        const float4* src = reinterpret_cast<const float4*>(A2f + (size_t)u * FC_RT * NKS * 64);
-        float4* dst = reinterpret_cast<float4*>(Af);
-        constexpr int N4 = FC_RT * NKS * 16;          // float4 count, all loads issued before stores
+        const int b = min(bt0 * 16 + c, Bs - 1);
+#pragma unroll
+        for (int s = 0; s < NK4; ++s) raw[s] = eu[min(4 * s + g, n - 1) * Bs + b];
+    }
+    {
+        // A fragments (prep2 wrote them in fragment order):
+        // Af[(t*NK4Q + sq)*64 + l].{x,y,z,w} = A2[16t + (l&15)][4*(4sq+e) + (l>>4)], e = 0..3
+        const float4* src = reinterpret_cast<const float4*>(A2f) + (size_t)u * FC_MT * NK4Q * 64;
+        constexpr int N4 = FC_MT * NK4Q * 64;
         float4 tv[(N4 + 255) / 256];
 #pragma unroll
         for (int i = 0; i < (N4 + 255) / 256; ++i)
             tv[i] = (tid + i * 256 < N4) ? src[tid + i * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < (N4 + 255) / 256; ++i)
-            if (tid + i * 256 < N4) dst[tid + i * 256] = tv[i];
+            if (tid + i * 256 < N4) Af[tid + i * 256] = tv[i];
     }
-    if (tid < 128) {
+    if (tid < FC_MT * 16) {
         sh2s[tid] = tid < FC_H ? sh2[(size_t)u * FC_H + tid] : 0.f;
         v2s[tid] = tid < FC_H ? V2[(size_t)u * FC_H + tid] : 0.f;
     }
+#pragma unroll
+    for (int s = 0; s < NK4; ++s) KEEP(raw[s]);
     __syncthreads();
     STAMP(1);
     const float a1 = alpha[u], s1 = shift[u];
     for (int it = 0; it < FC_BTW; ++it) {
-        const int bt = (blockIdx.x * 4 + wave) * FC_BTW + it;
-        const int b = bt * 32 + rc;
-        if (bt * 32 >= B) break;                       // wave-uniform
-        float qf[NKS];
-        // all loads first (unconditional, clamped rows), pinned, then exp: see KEEP in common.h
+        const int bt = bt0 + it;
+        if (bt * 16 >= B) break;                       // wave-uniform
+        const int b = bt * 16 + c;
+        float qf[NK4];
 #pragma unroll
-        for (int s = 0; s < NKS; ++s) qf[s] = ext[((size_t)u * n + min(2 * s + kk, n - 1)) * Bs + b];
+        for (int s = 0; s < NK4; ++s) qf[s] = (4 * s + g < n) ? qval(a1, raw[s], s1) : 0.f;
+        if (it + 1 < FC_BTW && (bt + 1) * 16 < B) {    // next tile's loads fly under this tile's MFMAs
+            const int bn = min(b + 16, Bs - 1);
 #pragma unroll
-        for (int s = 0; s < NKS; ++s) KEEP(qf[s]);
-#pragma unroll
-        for (int s = 0; s < NKS; ++s) qf[s] = (2 * s + kk < n) ? qval(a1, qf[s], s1) : 0.f;
+            for (int s = 0; s < NK4; ++s) raw[s] = eu[min(4 * s + g, n - 1) * Bs + bn];
+        }
         uint32_t rs = 0;
         if (MODE == 2)
-            rs = mix32(mix32(seed_lo ^ (uint32_t)(2 * b + kk) * 0x9E3779B9U) ^
+            rs = mix32(mix32(seed_lo ^ (uint32_t)(4 * b + g) * 0x9E3779B9U) ^
                        mix32(seed_hi + (uint32_t)u)) | 1u;
         const uint8_t* km = (MODE == 3) ? keep_mask + (size_t)min(b, B - 1) * FC_H * U + (size_t)u * FC_H
                                         : nullptr;
-        if (it == 0) STAMP_AFTER_LOADS(2);
+        if (it == 0) STAMP(2);
         float zp = 0.f;
-        uint32_t words[FC_RT];
+        uint32_t words[4] = {0u, 0u, 0u, 0u};
+        // channel tiles two at a time: two independent accumulator chains
 #pragma unroll
-        for (int t = 0; t < FC_RT; ++t) {
-            f32x16 acc;
+        for (int t0 = 0; t0 < FC_MT; t0 += 2) {
+            f32x4 acc[2];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 v = *reinterpret_cast<const float4*>(&sh2s[32 * t + 8 * g + 4 * kk]);
-                acc[4 * g] = v.x; acc[4 * g + 1] = v.y; acc[4 * g + 2] = v.z; acc[4 * g + 3] = v.w;
+            for (int tt = 0; tt < 2; ++tt) {
+                const int t = min(t0 + tt, FC_MT - 1);
+                const float4 v = *reinterpret_cast<const float4*>(&sh2s[16 * t + 4 * g]);
+                acc[tt][0] = v.x; acc[tt][1] = v.y; acc[tt][2] = v.z; acc[tt][3] = v.w;
             }
 #pragma unroll
-            for (int s = 0; s < NKS; ++s) acc = MFMA32(Af[(t * NKS + s) * 64 + lane], qf[s], acc);
-            uint32_t word = 0u;
+            for (int sq = 0; sq < NK4Q; ++sq) {
+                const float4 a0 = Af[(t0 * NK4Q + sq) * 64 + lane];
+                const float4 a1v = (t0 + 1 < FC_MT) ? Af[((t0 + 1) * NK4Q + sq) * 64 + lane] : a0;
+                const float a0a[4] = {a0.x, a0.y, a0.z, a0.w}, a1a[4] = {a1v.x, a1v.y, a1v.z, a1v.w};
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 v2 = *reinterpret_cast<const float4*>(&v2s[32 * t + 8 * g + 4 * kk]);
+                for (int e = 0; e < 4; ++e) {
+                    const int s = 4 * sq + e;
+                    if (s < NK4) {
+                        acc[0] = MFMA16(a0a[e], qf[s], acc[0]);
+                        if (t0 + 1 < FC_MT) acc[1] = MFMA16(a1a[e], qf[s], acc[1]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int t = t0 + tt;
+                if (t >= FC_MT) break;
+                const float4 v2 = *reinterpret_cast<const float4*>(&v2s[16 * t + 4 * g]);
                 const float v2a[4] = {v2.x, v2.y, v2.z, v2.w};
+                uint32_t nib = 0u;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float y = acc[4 * g + j];
+                    const float y = acc[tt][j];
                     bool pos = y > 0.f;
                     if (MODE == 2) {
                         uint32_t rnd;
@@ -121,21 +154,27 @@ __global__ __launch_bounds__(256, (NQ <= 32 ? 5 : 1)) void fc_fwd_kernel(
                         else rnd = rs >> 16;
                         pos = pos && (rnd >= thresh16);
                     } else if (MODE == 3) {
-                        const int r = 32 * t + 8 * g + 4 * kk + j;
+                        const int r = 16 * t + 4 * g + j;
                         pos = pos && (km[r < FC_H ? r : 0] != 0);
                     }
                     const float av = pos ? y * scale : 0.f;
                     zp = fmaf(v2a[j], av, zp);
-                    word |= (pos ? 1u : 0u) << (8 * g + 4 * kk + j);
+                    nib |= (pos ? 1u : 0u) << j;
                 }
+                // channel r = 16t + 4g + j is bit (r & 31) of word r >> 5
+                words[t >> 1] |= nib << (16 * (t & 1) + 4 * g);
             }
-            words[t] = word;
         }
         if (it == 0) STAMP(3);
+        // the four lane groups of a sequence hold disjoint channel sets: merge across g
+        zp += __shfl_xor(zp, 16, 64);
         zp += __shfl_xor(zp, 32, 64);
 #pragma unroll
-        for (int t = 0; t < FC_RT; ++t) words[t] |= __shfl_xor(words[t], 32, 64);
-        if (kk == 0) {
+        for (int k = 0; k < 4; ++k) {
+            words[k] |= __shfl_xor(words[k], 16, 64);
+            words[k] |= __shfl_xor(words[k], 32, 64);
+        }
+        if (g == 0 && b < Bs) {
             if (TRAIN) {
                 zout[(size_t)u * Bs + b] = zp;
                 bits[(size_t)u * Bs + b] = make_uint4(words[0], words[1], words[2], words[3]);
@@ -149,9 +188,14 @@ __global__ __launch_bounds__(256, (NQ <= 32 ? 5 : 1)) void fc_fwd_kernel(
     STAMP(4);
 }
 
+template <int NQ>
+static size_t fc_fwd_lds() {
+    return (size_t)(FC_MT * fc_nk4q(NQ) * 64 * 4 + 2 * FC_MT * 16) * sizeof(float);
+}
+
 int launch_fc_fwd(explainn_ctx* c, const explainn_params* p, int B, bool train,
                   const uint8_t* keep_mask, float drop_p, uint64_t seed, hipStream_t s) {
-    const int tiles = (B + 31) / 32;
+    const int tiles = (B + 15) / 16;
     const dim3 grid((tiles + 4 * FC_BTW - 1) / (4 * FC_BTW), c->U);
     int mode = train ? 1 : 0;
     float scale = 1.f;
@@ -168,10 +212,10 @@ int launch_fc_fwd(explainn_ctx* c, const explainn_params* p, int B, bool train,
              (c->capturing ? c->seed_dev : (const uint32_t*)nullptr)
 #define CALL(N)                                                                                    \
     switch (mode) {                                                                                \
-        case 0: hipLaunchKernelGGL((fc_fwd_kernel<N, 0>), grid, dim3(256), 0, s, ARGS); break;     \
-        case 1: hipLaunchKernelGGL((fc_fwd_kernel<N, 1>), grid, dim3(256), 0, s, ARGS); break;     \
-        case 2: hipLaunchKernelGGL((fc_fwd_kernel<N, 2>), grid, dim3(256), 0, s, ARGS); break;     \
-        default: hipLaunchKernelGGL((fc_fwd_kernel<N, 3>), grid, dim3(256), 0, s, ARGS); break;    \
+        case 0: hipLaunchKernelGGL((fc_fwd_kernel<N, 0>), grid, dim3(256), fc_fwd_lds<N>(), s, ARGS); break; \
+        case 1: hipLaunchKernelGGL((fc_fwd_kernel<N, 1>), grid, dim3(256), fc_fwd_lds<N>(), s, ARGS); break; \
+        case 2: hipLaunchKernelGGL((fc_fwd_kernel<N, 2>), grid, dim3(256), fc_fwd_lds<N>(), s, ARGS); break; \
+        default: hipLaunchKernelGGL((fc_fwd_kernel<N, 3>), grid, dim3(256), fc_fwd_lds<N>(), s, ARGS); break; \
     }
     NQ_DISPATCH(c->NQ, CALL);
 #undef CALL
@@ -181,14 +225,16 @@ int launch_fc_fwd(explainn_ctx* c, const explainn_params* p, int B, bool train,
 }
 
 // ---------------------------------------------------------------------------------------------
-// passA: one wavefront per (unit, batch chunk, w-tile); K dimension = sequences, two per MFMA.
-// Super-tiles of 64 sequences are fetched with coalesced loads (lane = sequence): the q rows
-// (from ext, through exp), the 128 bit words and dz; they are re-read from a wave-private LDS tile
-// in MFMA operand order while the next super-tile's loads are already in flight.
+// passA: one wavefront per (unit, batch chunk, group of w tiles); K dimension = sequences, four
+// per MFMA.  Super-tiles of 64 sequences are fetched with coalesced loads (lane = sequence): the q
+// rows (from ext, through exp), the bit words and dz; they are re-read from a wave-private LDS
+// tile in MFMA operand order while the next super-tile's loads are already in flight.  The row
+// stride 68 makes the operand reads conflict-free: bank = (4 row + column) mod 64 with 16 rows x 4
+// columns per read.
 // ---------------------------------------------------------------------------------------------
-#define QT_LD 65
+#define QT_LD 68
 template <int NQ>
-__global__ __launch_bounds__(64, 3) void passA_kernel(const float* __restrict__ ext,
+__global__ __launch_bounds__(64) void passA_kernel(const float* __restrict__ ext,
                                                    const float* __restrict__ alpha,
                                                    const float* __restrict__ shift,
                                                    const float* __restrict__ dz,
@@ -196,86 +242,101 @@ __global__ __launch_bounds__(64, 3) void passA_kernel(const float* __restrict__ 
                                                    float* __restrict__ EQp,
                                                    float* __restrict__ Sep, int n, int Bs, int B,
                                                    int ACH) {
-    constexpr int NS = ns_stride(NQ);
-    __shared__ float tq[32 * QT_LD];
+    constexpr int NS = ns_stride(NQ), NW16 = fc_nw16(NQ), WGT = fc_wgt(NQ), ROWS = 16 * WGT;
+    __shared__ float tq[ROWS * QT_LD];
     __shared__ __attribute__((aligned(16))) uint4 tw[64];
     __shared__ float tdz[64];
-    const int u = blockIdx.y, ch = blockIdx.x, wt = blockIdx.z, lane = threadIdx.x;
-    const int rc = lane & 31, kk = lane >> 5;
+    const int u = blockIdx.y, ch = blockIdx.x, grp = blockIdx.z, lane = threadIdx.x;
+    const int c = lane & 15, g = lane >> 4;
+    const int w0 = grp * ROWS;                         // first pooled position of this group
     const int per = ((((B + ACH - 1) / ACH) + 63) / 64) * 64;
     const int bbeg = ch * per, bend = min(B, bbeg + per);
     const float a1 = alpha[u], sh1 = shift[u];
-    const float* eu = ext + (size_t)u * n * Bs;
-    const float* dzu = dz + (size_t)u * Bs;
-    const uint4* bu = bits + (size_t)u * Bs;
-    f32x16 acc[FC_RT];
+    const float* __restrict__ eu = ext + (size_t)u * n * Bs;
+    const float* __restrict__ dzu = dz + (size_t)u * Bs;
+    const uint4* __restrict__ bu = bits + (size_t)u * Bs;
+    f32x4 acc[FC_MT][WGT];
 #pragma unroll
-    for (int t = 0; t < FC_RT; ++t)
+    for (int t = 0; t < FC_MT; ++t)
 #pragma unroll
-        for (int g = 0; g < 16; ++g) acc[t][g] = 0.f;
-    float se[FC_RT] = {0.f, 0.f, 0.f, 0.f};
-    float rq[32], rdz = 0.f;
+        for (int j = 0; j < WGT; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[t][j][i] = 0.f;
+    float se[FC_MT];
+#pragma unroll
+    for (int t = 0; t < FC_MT; ++t) se[t] = 0.f;
+    float rq[ROWS], rdz = 0.f;
     uint4 rw = make_uint4(0u, 0u, 0u, 0u);
     auto fetch = [&](int b0) {
         const int b = b0 + lane;
         const bool live = b < bend;
         const int bc = live ? b : bbeg;
 #pragma unroll
-        for (int i = 0; i < 32; ++i) rq[i] = eu[(size_t)min(wt * 32 + i, n - 1) * Bs + bc];
+        for (int i = 0; i < ROWS; ++i) rq[i] = eu[min(w0 + i, n - 1) * Bs + bc];
         rdz = dzu[bc];
         rw = bu[bc];
 #pragma unroll
-        for (int i = 0; i < 32; ++i) KEEP(rq[i]);
+        for (int i = 0; i < ROWS; ++i) KEEP(rq[i]);
         KEEP(rdz);
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            const int w = wt * 32 + i;
-            rq[i] = (live && w < n) ? qval(a1, rq[i], sh1) : 0.f;
-        }
+        for (int i = 0; i < ROWS; ++i) rq[i] = (live && w0 + i < n) ? qval(a1, rq[i], sh1) : 0.f;
         rdz = live ? rdz : 0.f;
     };
     STAMP(0);
     if (bbeg < bend) fetch(bbeg);
     for (int b0 = bbeg; b0 < bend; b0 += 64) {
 #pragma unroll
-        for (int i = 0; i < 32; ++i) tq[i * QT_LD + lane] = rq[i];
+        for (int i = 0; i < ROWS; ++i) tq[i * QT_LD + lane] = rq[i];
         tw[lane] = rw;
         tdz[lane] = rdz;
         if (b0 == bbeg) STAMP(1);
         if (b0 + 64 < bend) fetch(b0 + 64);           // in flight during the MFMAs below
-        const int ks = (min(bend - b0, 64) + 1) >> 1;
-        for (int s = 0; s < ks; ++s) {
-            const int col = 2 * s + kk;
-            const float qv = tq[rc * QT_LD + col];
+        // always the 16 k-steps of a super-tile (sequences past the chunk end carry dz = 0)
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {
+            const int col = 4 * s + g;
+            float qv[WGT];
+#pragma unroll
+            for (int j = 0; j < WGT; ++j) qv[j] = tq[(16 * j + c) * QT_LD + col];
             const float dzb = tdz[col];
             const uint4 wv = tw[col];
-            const uint32_t wds[FC_RT] = {wv.x, wv.y, wv.z, wv.w};
+            // bit of channel r = 16t + c: word t>>1, bit 16(t&1) + c -> shift by c once per word
+            const uint32_t wds[4] = {wv.x >> c, wv.y >> c, wv.z >> c, wv.w >> c};
+            const uint32_t dzbits = __float_as_uint(dzb);
 #pragma unroll
-            for (int t = 0; t < FC_RT; ++t) {
-                const float e = ((wds[t] >> rc) & 1u) ? dzb : 0.f;
+            for (int t = 0; t < FC_MT; ++t) {
+                const int m = __builtin_amdgcn_sbfe(wds[t >> 1], 16 * (t & 1), 1);      // 0 or -1
+                const float e = __uint_as_float(dzbits & (uint32_t)m);
                 se[t] += e;
-                acc[t] = MFMA32(e, qv, acc[t]);
+#pragma unroll
+                for (int j = 0; j < WGT; ++j) acc[t][j] = MFMA16(e, qv[j], acc[t][j]);
             }
         }
     }
     STAMP(2);
-    // D[r][w]: lane holds column w = wt*32+rc, rows r = 32t + (g&3) + 8(g>>2) + 4kk
-    const int w = wt * 32 + rc;
-    if (w < NS) {
+    // D[r][w]: lane holds column w = w0 + 16j + c, rows r = 16t + 4g + i
 #pragma unroll
-        for (int t = 0; t < FC_RT; ++t)
+    for (int j = 0; j < WGT; ++j) {
+        const int w = w0 + 16 * j + c;
+        if (w < NS) {
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int r = 32 * t + (g & 3) + 8 * (g >> 2) + 4 * kk;
-                if (r < FC_H) EQp[(((size_t)u * ACH + ch) * FC_H + r) * NS + w] = acc[t][g];
-            }
+            for (int t = 0; t < FC_MT; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 16 * t + 4 * g + i;
+                    if (r < FC_H) EQp[(((size_t)u * ACH + ch) * FC_H + r) * NS + w] = acc[t][j][i];
+                }
+        }
     }
-    if (wt == 0) {
+    if (grp == 0) {
+        // se[t] of lane (g, c) = sum over the sequences 4s+g of e[.][16t + c]: add the four groups
 #pragma unroll
-        for (int t = 0; t < FC_RT; ++t) {
-            const float sv = se[t] + __shfl_xor(se[t], 32, 64);
-            const int r = 32 * t + rc;
-            if (kk == 0 && r < FC_H) Sep[((size_t)u * ACH + ch) * FC_H + r] = sv;
+        for (int t = 0; t < FC_MT; ++t) {
+            float sv = se[t];
+            sv += __shfl_xor(sv, 16, 64);
+            sv += __shfl_xor(sv, 32, 64);
+            const int r = 16 * t + c;
+            if (g == 0 && r < FC_H) Sep[((size_t)u * ACH + ch) * FC_H + r] = sv;
         }
     }
     STAMP(3);
@@ -283,7 +344,7 @@ __global__ __launch_bounds__(64, 3) void passA_kernel(const float* __restrict__ 
 
 int launch_passA(explainn_ctx* c, int B, hipStream_t s) {
 #define CALL(N)                                                                                  \
-    hipLaunchKernelGGL(passA_kernel<N>, dim3(c->ACH, c->U, (N + 31) / 32), dim3(64), 0, s,       \
+    hipLaunchKernelGGL(passA_kernel<N>, dim3(c->ACH, c->U, fc_ng(N)), dim3(64), 0, s,            \
                        c->ext, c->alpha, c->shift, c->dz, c->bits, c->EQp, c->Sep, c->n, c->Bs,  \
                        B, c->ACH)
     NQ_DISPATCH(c->NQ, CALL);
@@ -293,45 +354,57 @@ int launch_passA(explainn_ctx* c, int B, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// passB: workgroup = 4 wavefronts of one unit; T and M fragments staged in LDS
+// passB: workgroup = 4 wavefronts of one (unit, group of w tiles); T and M fragments staged in LDS.
+// k order of the M.q product: step (j', i') of lane (g, c) carries v = 16j' + 4g + i' -- exactly the
+// rows 16j + 4g + i the lane's accumulators hold, so the epilogue's q values are the operand
+// registers themselves.
 // ---------------------------------------------------------------------------------------------
 template <int NQ>
-__global__ __launch_bounds__(256, (NQ <= 32 ? 5 : 1)) void passB_kernel(
+__global__ __launch_bounds__(256) void passB_kernel(
     const float* __restrict__ ext, const float* __restrict__ alpha,
     const float* __restrict__ shift, const float* __restrict__ dz, const uint4* __restrict__ bits,
     const float* __restrict__ Ttf, const float* __restrict__ Mff, const float* __restrict__ k0p,
     const double* __restrict__ mug, const double* __restrict__ sig1, float* __restrict__ dy,
     float* __restrict__ S12p, int n, int Bs, int B) {
-    constexpr int NS = ns_stride(NQ), NKS = (NQ + 1) / 2, NWT = (NQ + 31) / 32, RKS = FC_H / 2;
+    constexpr int NS = ns_stride(NQ), NW16 = fc_nw16(NQ), WGT = fc_wgt(NQ), NG = fc_ng(NQ);
+    constexpr int RK4 = FC_H / 4, MK = 4 * NW16;       // k-steps of the T.e and of the M.q product
     extern __shared__ __attribute__((aligned(16))) float smemB[];
-    float* Tf = smemB;                                 // [NWT][RKS][64]
-    float* Mf = Tf + NWT * RKS * 64;                   // [NWT][NKS][64]
-    float* k0s = Mf + NWT * NKS * 64;                  // [NWT*32]
-    const int u = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rc = lane & 31, kk = lane >> 5;
+    float* Tf = smemB;                                 // [WGT][RK4][64]
+    float* Mf = Tf + WGT * RK4 * 64;                   // [WGT][MK][64]
+    float* k0s = Mf + WGT * MK * 64;                   // [WGT*16]
+    const int u = blockIdx.y, grp = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int j0 = grp * WGT;                          // first w tile of this group
+    const int ntile = min(WGT, NW16 - j0);             // w tiles this group really has
     STAMP(0);
-    // A fragments Tf[(wt*RKS+s)*64+l] = T[r=2s+(l>>5)][w=wt*32+(l&31)] and Mf likewise over v are
-    // laid out by the mid kernels (Ttf/Mff); copy them with float4, all loads before the stores
+    // A fragments Tf[(j*RK4+s)*64+l] = T[r=4s+(l>>4)][w=16(j0+j)+(l&15)], Mf[(j*MK+kq)*64+l] =
+    // M[v=16(kq>>2)+4(l>>4)+(kq&3)][w=16(j0+j)+(l&15)] are laid out by the mid kernels; copy them
+    // with float4, all loads before the stores
     {
-        constexpr int NT4 = NWT * RKS * 16, NM4 = NWT * NKS * 16, N4 = NT4 + NM4;
-        const float4* srcT = reinterpret_cast<const float4*>(Ttf + (size_t)u * NWT * RKS * 64);
-        const float4* srcM = reinterpret_cast<const float4*>(Mff + (size_t)u * NWT * NKS * 64);
+        constexpr int NT4 = WGT * RK4 * 16, NM4 = WGT * MK * 16, N4 = NT4 + NM4;
+        const float4* srcT = reinterpret_cast<const float4*>(Ttf + ((size_t)u * NW16 + j0) * RK4 * 64);
+        const float4* srcM = reinterpret_cast<const float4*>(Mff + ((size_t)u * NW16 + j0) * MK * 64);
+        const int lim_t = ntile * RK4 * 16, lim_m = ntile * MK * 16;
         float4* dst = reinterpret_cast<float4*>(Tf);  // Mf follows Tf contiguously
         float4 tv[(N4 + 255) / 256];
 #pragma unroll
         for (int i = 0; i < (N4 + 255) / 256; ++i) {
             const int e = tid + i * 256;
-            tv[i] = e < NT4 ? srcT[e] : (e < N4 ? srcM[e - NT4] : make_float4(0.f, 0.f, 0.f, 0.f));
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < NT4) { if (e < lim_t) v = srcT[e]; }
+            else if (e < N4) { if (e - NT4 < lim_m) v = srcM[e - NT4]; }
+            tv[i] = v;
         }
 #pragma unroll
         for (int i = 0; i < (N4 + 255) / 256; ++i)
             if (tid + i * 256 < N4) dst[tid + i * 256] = tv[i];
     }
-    for (int i = tid; i < NWT * 32; i += 256) k0s[i] = (i < NS) ? k0p[(size_t)u * NS + i] : 0.f;
+    for (int i = tid; i < WGT * 16; i += 256) {
+        const int w = 16 * j0 + i;
+        k0s[i] = (w < NS) ? k0p[(size_t)u * NS + w] : 0.f;
+    }
     __syncthreads();
     STAMP(1);
-    // wave-uniform bases + 32-bit lane offsets (saddr addressing): 64-bit per-row addresses were
-    // hoisted out of the tile loop and spilled (200 B/lane of scratch at the 5-waves/SIMD budget)
     const float* __restrict__ eu = ext + (size_t)u * n * Bs;
     float* __restrict__ dyu = dy + (size_t)u * n * Bs;
     const float a1 = alpha[u], s1 = shift[u];
@@ -339,69 +412,71 @@ __global__ __launch_bounds__(256, (NQ <= 32 ? 5 : 1)) void passB_kernel(
     const float isg = (float)(1.0 / sig1[u]);
     for (int it = 0; it < PB_BTW; ++it) {
         const int bt = (blockIdx.x * 4 + wave) * PB_BTW + it;
-        if (bt * 32 >= B) break;                       // wave-uniform
-        const int b = bt * 32 + rc;
+        if (bt * 16 >= B) break;                       // wave-uniform
+        const int b = bt * 16 + c;
         const bool live = b < B;
-        // raw pooled extremes of this lane's sequence, rows w = 2s + kk: the MFMA B operand (-q) is
-        // derived from them, and so is the epilogue's ex -- the D layout wants rows
-        // wt*32 + (g&3) + 8(g>>2) + 4kk, which this lane or its partner in the other half-wave holds
-        float exr[NKS];
+        const int bc = min(b, Bs - 1);
+        // raw pooled extremes of this lane's sequence, rows v = 16j' + 4g + i' (register kq = 4j'+i')
+        float exr[MK];
 #pragma unroll
-        for (int s = 0; s < NKS; ++s) exr[s] = eu[min(2 * s + kk, n - 1) * Bs + b];
+        for (int kq = 0; kq < MK; ++kq) exr[kq] = eu[min(16 * (kq >> 2) + 4 * g + (kq & 3), n - 1) * Bs + bc];
+        const uint4 wv = bits[(size_t)u * Bs + bc];
+        const float dzb = dz[(size_t)u * Bs + bc];
 #pragma unroll
-        for (int s = 0; s < NKS; ++s) KEEP(exr[s]);
-        const uint4 wv = bits[(size_t)u * Bs + b];
-        const float dzb = dz[(size_t)u * Bs + b];
-        const uint32_t wds[4] = {wv.x, wv.y, wv.z, wv.w};
+        for (int kq = 0; kq < MK; ++kq) KEEP(exr[kq]);
+        // channel r = 4s + g: word (4s)>>5, bit (4s & 31) + g -> shift by g once per word
+        const uint32_t wds[4] = {wv.x >> g, wv.y >> g, wv.z >> g, wv.w >> g};
+        const uint32_t dzbits = __float_as_uint(dzb);
+        float nq[MK];
+#pragma unroll
+        for (int kq = 0; kq < MK; ++kq)
+            nq[kq] = (16 * (kq >> 2) + 4 * g + (kq & 3) < n) ? -qval(a1, exr[kq], s1) : 0.f;
         float sA = 0.f, sB = 0.f;
         if (it == 0) STAMP_AFTER_LOADS(2);
+        f32x4 acc[WGT];
 #pragma unroll
-        for (int wt = 0; wt < NWT; ++wt) {
-            f32x16 acc;
+        for (int j = 0; j < WGT; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(&k0s[16 * j + 4 * g]);
+            acc[j][0] = -v.x; acc[j][1] = -v.y; acc[j][2] = -v.z; acc[j][3] = -v.w;
+        }
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 v = *reinterpret_cast<const float4*>(&k0s[wt * 32 + 8 * g + 4 * kk]);
-                acc[4 * g] = -v.x; acc[4 * g + 1] = -v.y; acc[4 * g + 2] = -v.z; acc[4 * g + 3] = -v.w;
-            }
+        for (int s = 0; s < RK4; ++s) {
+            const int m = __builtin_amdgcn_sbfe(wds[s >> 3], 4 * (s & 7), 1);           // 0 or -1
+            const float e = __uint_as_float(dzbits & (uint32_t)m);
 #pragma unroll
-            for (int s = 0; s < RKS; ++s) {
-                const float e = (((wds[s >> 4] >> ((2 * s) & 31)) >> kk) & 1u) ? dzb : 0.f;
-                acc = MFMA32(Tf[(wt * RKS + s) * 64 + lane], e, acc);
-            }
+            for (int j = 0; j < WGT; ++j) acc[j] = MFMA16(Tf[(j * RK4 + s) * 64 + lane], e, acc[j]);
+        }
 #pragma unroll
-            for (int s = 0; s < NKS; ++s) {
-                const float nq = (2 * s + kk < n) ? -qval(a1, exr[s], s1) : 0.f;
-                acc = MFMA32(Mf[(wt * NKS + s) * 64 + lane], nq, acc);
-            }
-            if (it == 0 && wt == 0) STAMP(3);
-            // D[w][b]: lane holds its sequence b, rows w = wt*32 + (g&3) + 8(g>>2) + 4kk.  Row w
-            // lives in exr[w>>1] of the half-wave with kk = w&1 = g&1: own register for that half,
-            // the partner's (lane ^ 32) for the other -- no second read of ext.
+        for (int kq = 0; kq < MK; ++kq)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int wbase = wt * 32 + (g & 3) + 8 * (g >> 2);     // row of the kk = 0 half
-                const int s0 = min(wbase >> 1, NKS - 1), s1i = min((wbase + 4) >> 1, NKS - 1);
-                float ex;
-                if ((g & 1) == 0) {          // even rows are held by kk = 0 lanes
-                    const float fromPartner = __shfl_xor(exr[s1i], 32, 64);
-                    ex = kk ? fromPartner : exr[s0];
-                } else {                     // odd rows by kk = 1 lanes
-                    const float fromPartner = __shfl_xor(exr[s0], 32, 64);
-                    ex = kk ? exr[s1i] : fromPartner;
+            for (int j = 0; j < WGT; ++j) acc[j] = MFMA16(Mf[(j * MK + kq) * 64 + lane], nq[kq], acc[j]);
+        if (it == 0) STAMP(3);
+        // D[w][b]: lane holds its sequence b, rows w = 16(j0+j) + 4g + i = the v of register 4(j0+j)+i
+#pragma unroll
+        for (int j = 0; j < WGT; ++j) {
+            if (j >= ntile) break;                     // block-uniform
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // register index 4(j0+j)+i: j0 is a multiple of WGT and the loop is unrolled, but j0
+                // is a runtime value -> select among the NG candidates (compile-time indices)
+                float nqv = 0.f, ex = 0.f;
+#pragma unroll
+                for (int gg = 0; gg < NG; ++gg) {
+                    const int kq = 4 * (gg * WGT + j) + i;
+                    if (kq < MK && gg == grp) { nqv = nq[kq]; ex = exr[kq]; }
                 }
-                const int w = wbase + 4 * kk;
-                const float qv = qval(a1, ex, s1);
-                const float dyv = (live && w < n) ? acc[g] * qv : 0.f;
+                const int w = 16 * (j0 + j) + 4 * g + i;
+                const float dyv = (live && w < n) ? -acc[j][i] * nqv : 0.f;      // dq * q
                 sA += dyv;
                 sB = fmaf(dyv, (ex - mu) * isg, sB);
-                if (w < n) dyu[w * Bs + b] = dyv;
+                if (w < n && b < Bs) dyu[w * Bs + b] = dyv;
             }
         }
         if (it == 0) STAMP(4);
         sA = wave_sum(sA);
         sB = wave_sum(sB);
         if (lane == 0) {
-            float* d = S12p + ((size_t)u * (Bs / 32) + bt) * 2;
+            float* d = S12p + (((size_t)u * NG + grp) * (Bs / 16) + bt) * 2;
             d[0] = sA; d[1] = sB;
         }
     }
@@ -410,15 +485,15 @@ __global__ __launch_bounds__(256, (NQ <= 32 ? 5 : 1)) void passB_kernel(
 
 template <int NQ>
 static size_t passB_lds() {
-    constexpr int NKS = (NQ + 1) / 2, NWT = (NQ + 31) / 32;
-    return (size_t)(NWT * (FC_H / 2) * 64 + NWT * NKS * 64 + NWT * 32) * sizeof(float);
+    constexpr int WGT = fc_wgt(NQ), MK = 4 * fc_nw16(NQ);
+    return (size_t)(WGT * (FC_H / 4) * 64 + WGT * MK * 64 + WGT * 16) * sizeof(float);
 }
 
 int launch_passB(explainn_ctx* c, int B, hipStream_t s) {
-    const int tiles = (B + 31) / 32;
-    const dim3 grid((tiles + 4 * PB_BTW - 1) / (4 * PB_BTW), c->U);
+    const int tiles = (B + 15) / 16;
 #define CALL(N)                                                                                  \
-    hipLaunchKernelGGL(passB_kernel<N>, grid, dim3(256), passB_lds<N>(), s, c->ext, c->alpha,    \
+    hipLaunchKernelGGL(passB_kernel<N>, dim3((tiles + 4 * PB_BTW - 1) / (4 * PB_BTW), c->U, fc_ng(N)), \
+                       dim3(256), passB_lds<N>(), s, c->ext, c->alpha,                           \
                        c->shift, c->dz, c->bits, c->Ttf, c->Mff, c->k0p, c->mug, c->sig1, c->dy,    \
                        c->S12p, c->n, c->Bs, B)
     NQ_DISPATCH(c->NQ, CALL);
@@ -432,7 +507,17 @@ int fc_configure(explainn_ctx* c) {
     if (passB_lds<N>() > 48 * 1024)                                                          \
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&passB_kernel<N>),          \
                                     hipFuncAttributeMaxDynamicSharedMemorySize,              \
-                                    (int)passB_lds<N>()))
+                                    (int)passB_lds<N>()));                                   \
+    if (fc_fwd_lds<N>() > 48 * 1024) {                                                       \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_fwd_kernel<N, 0>),      \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)fc_fwd_lds<N>())); \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_fwd_kernel<N, 1>),      \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)fc_fwd_lds<N>())); \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_fwd_kernel<N, 2>),      \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)fc_fwd_lds<N>())); \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_fwd_kernel<N, 3>),      \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)fc_fwd_lds<N>())); \
+    }
     NQ_DISPATCH(c->NQ, CALL);
 #undef CALL
     return EXPLAINN_OK;

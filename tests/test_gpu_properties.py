@@ -46,9 +46,11 @@ def _knife_masks(cache, U_):
     return ch, un
 
 
-def _compare_masked(named_grads, ref, cache, U_, tight=2e-4, loose=1e-2):
+def _compare_masked(named_grads, ref, cache, U_, tight=5e-5, loose=5e-2):
     """Every gradient against the oracle: `tight` x max|ref| everywhere except the knife-edge
-    channels / units of _knife_masks, which only have to stay within `loose`."""
+    channels / units of _knife_masks, which only have to stay within `loose` (a flipped branch moves
+    a row by one sample's share, which can be a percent of a small tensor's max: 1.1e-2 seen at
+    T = 164).  Measured on MI355X: clean entries agree to 1e-6 .. 3e-6 of the tensor's max."""
     ch, un = _knife_masks(cache, U_)
     # the masks must stay a small exception: under 2 % of the channels, and enough clean units left
     # for the tight comparison to mean something (an indexing bug hits every unit alike)
