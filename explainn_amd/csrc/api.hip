@@ -56,7 +56,7 @@ void carve(explainn_ctx* c, Carver& cv) {
     cv.take(&c->qbar, U * NS);
     cv.take(&c->VC, U * FC_H * NS);
     cv.take(&c->A2, U * FC_H * NS);
-    cv.take(&c->A2f, U * 4 * ((c->NQ + 1) / 2) * 64);
+    cv.take(&c->A2f, U * FC_MT * fc_nk4q(c->NQ) * 256);
     cv.take(&c->sh2, U * FC_H);
     cv.take(&c->sig2, U * FC_H);
     cv.take(&c->z, U * Bs);
@@ -70,11 +70,11 @@ void carve(explainn_ctx* c, Carver& cv) {
     cv.take(&c->EQs, U * FC_H * NS);
     cv.take(&c->Tt, (U * FC_H + 2) * NS);
     cv.take(&c->M, (U * NS + 2) * NS);
-    cv.take(&c->Ttf, U * ((c->NQ + 31) / 32) * (FC_H / 2) * 64);
-    cv.take(&c->Mff, U * ((c->NQ + 31) / 32) * ((c->NQ + 1) / 2) * 64);
+    cv.take(&c->Ttf, U * fc_nw16(c->NQ) * (FC_H / 4) * 64);
+    cv.take(&c->Mff, U * fc_nw16(c->NQ) * 4 * fc_nw16(c->NQ) * 64);
     cv.take(&c->k0p, U * NS);
     cv.take(&c->dy, U4 * n * Bs);
-    cv.take(&c->S12p, U * (Bs / 32) * 2);
+    cv.take(&c->S12p, U * fc_ng(c->NQ) * (Bs / 16) * 2);
     cv.take(&c->Dspp, U * (Bs / 64) * K4);
     cv.take(&c->dlogits, (int64_t)c->maxB * c->T);
     cv.take(&c->flags, 64);

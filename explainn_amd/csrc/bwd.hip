@@ -27,7 +27,7 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
     const float* __restrict__ VC, float* __restrict__ Tt, float* __restrict__ Ttf,
     float* __restrict__ M, float* __restrict__ Mff, float* __restrict__ k0p, float* __restrict__ g_fc2_w, float* __restrict__ g_bn2_w,
     float* __restrict__ g_bn2_b, float* __restrict__ g_fc1_b, float* __restrict__ g_fc1_w, int n,
-    int NS, int NWT, int NKS, int B, int ACH, float scale) {
+    int NS, int NW16, int B, int ACH, float scale) {
     extern __shared__ float fsm[];
     const int ld = n + 1;
     float* V1s = fsm;                        // [100][ld]
@@ -127,8 +127,9 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
                     const int v = 32 * vt + (g & 3) + 8 * (g >> 2) + 4 * kk;
                     if (v < NS) {
                         M[(size_t)u * NS * NS + (size_t)v * NS + wb] = acc[g];
-                        if ((v >> 1) < NKS)
-                            Mff[(size_t)u * NWT * NKS * 64 + ((size_t)(wb >> 5) * NKS + (v >> 1)) * 64 + (v & 1) * 32 + (wb & 31)] = acc[g];
+                        if (v < 16 * NW16 && wb < 16 * NW16)       // k order (j', i'): v = 16j' + 4g + i'
+                            Mff[(((size_t)u * NW16 + (wb >> 4)) * (4 * NW16) + 4 * (v >> 4) + (v & 3)) * 64 +
+                                16 * ((v >> 2) & 3) + (wb & 15)] = acc[g];
                         if (v < n && wb < n) Ms[v * n + wb] = acc[g];
                     }
                 }
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
             g_fc1_w[ch * n + w] = (float)val;
         }
         Tt[ch * NS + w] = tv;
-        Ttf[(size_t)u * NWT * (FC_H / 2) * 64 + ((size_t)(w >> 5) * (FC_H / 2) + (r >> 1)) * 64 + (r & 1) * 32 + (w & 31)] = tv;
+        Ttf[(((size_t)u * NW16 + (w >> 4)) * (FC_H / 4) + (r >> 2)) * 64 + 16 * (r & 3) + (w & 15)] = tv;
     }
     __syncthreads();
     STAMP(4);
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(1024) void mid_big_kernel(
     float* __restrict__ Ttf, float* __restrict__ M, float* __restrict__ Mff,
     float* __restrict__ k0p, float* __restrict__ g_fc2_w, float* __restrict__ g_bn2_w,
     float* __restrict__ g_bn2_b, float* __restrict__ g_fc1_b, float* __restrict__ g_fc1_w, int n,
-    int NS, int NWT, int NKS, int B, int ACH, float scale) {
+    int NS, int NW16, int B, int ACH, float scale) {
     extern __shared__ float bsm[];
     const int ld = n + 1;
     float* V1s = bsm;                        // [100][ld]
@@ -284,8 +285,9 @@ __global__ __launch_bounds__(1024) void mid_big_kernel(
                     const int v = 32 * vt + (g & 3) + 8 * (g >> 2) + 4 * kk;
                     if (v < NS) {
                         M[(size_t)u * NS * NS + (size_t)v * NS + wb] = acc[g];
-                        if ((v >> 1) < NKS)
-                            Mff[(size_t)u * NWT * NKS * 64 + ((size_t)(wb >> 5) * NKS + (v >> 1)) * 64 + (v & 1) * 32 + (wb & 31)] = acc[g];
+                        if (v < 16 * NW16 && wb < 16 * NW16)       // k order (j', i'): v = 16j' + 4g + i'
+                            Mff[(((size_t)u * NW16 + (wb >> 4)) * (4 * NW16) + 4 * (v >> 4) + (v & 3)) * 64 +
+                                16 * ((v >> 2) & 3) + (wb & 15)] = acc[g];
                     }
                 }
             }
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(1024) void mid_big_kernel(
             g_fc1_w[ch * n + w] = (float)val;
         }
         Tt[ch * NS + w] = tv;
-        Ttf[(size_t)u * NWT * (FC_H / 2) * 64 + ((size_t)(w >> 5) * (FC_H / 2) + (r >> 1)) * 64 + (r & 1) * 32 + (w & 31)] = tv;
+        Ttf[(((size_t)u * NW16 + (w >> 4)) * (FC_H / 4) + (r >> 2)) * 64 + 16 * (r & 3) + (w & 15)] = tv;
     }
     for (int w = tid; w < NS; w += NT) {
         double k0 = 0;
@@ -332,7 +334,7 @@ int launch_mid_bwd(explainn_ctx* c, const explainn_params* p, const explainn_gra
         hipLaunchKernelGGL(mid_fused_kernel, dim3(c->U), dim3(1024), mid_fused_lds(c->n), s, c->EQp,
                            c->Sep, c->A2, c->sh2, c->sig2, p->fc1_w, p->fc2_w, p->bn2_w, c->qbar,
                            c->VC, c->Tt, c->Ttf, c->M, c->Mff, c->k0p, g->fc2_w, g->bn2_w, g->bn2_b,
-                           g->fc1_b, g->fc1_w, c->n, c->NS, (c->NQ + 31) / 32, (c->NQ + 1) / 2, B, c->ACH,
+                           g->fc1_b, g->fc1_w, c->n, c->NS, fc_nw16(c->NQ), B, c->ACH,
                            c->fwd_scale);
         LAUNCH_CHECK();
         return EXPLAINN_OK;
@@ -340,7 +342,7 @@ int launch_mid_bwd(explainn_ctx* c, const explainn_params* p, const explainn_gra
     hipLaunchKernelGGL(mid_big_kernel, dim3(c->U), dim3(1024), mid_big_lds(c->n), s, c->EQp, c->Sep,
                        c->A2, c->sh2, c->sig2, p->fc1_w, p->fc2_w, p->bn2_w, c->qbar, c->VC, c->EQs,
                        c->Tt, c->Ttf, c->M, c->Mff, c->k0p, g->fc2_w, g->bn2_w, g->bn2_b, g->fc1_b,
-                       g->fc1_w, c->n, c->NS, (c->NQ + 31) / 32, (c->NQ + 1) / 2, B, c->ACH,
+                       g->fc1_w, c->n, c->NS, fc_nw16(c->NQ), B, c->ACH,
                        c->fwd_scale);
     LAUNCH_CHECK();
     return EXPLAINN_OK;
@@ -352,20 +354,21 @@ int launch_mid_bwd(explainn_ctx* c, const explainn_params* p, const explainn_gra
 struct fin_args {
     const float* S12p; const double* m; const double* Gw; const double* mug; const double* sig1;
     const float* g1; float* g_conv_w; float* g_conv_b; float* g_bn1_w; float* g_bn1_b;
-    int K4; int freeze_n;
+    int K4; int freeze_n; int NG;
 };
 
 __device__ __forceinline__ void fin_unit(const fin_args& f, const float* __restrict__ Dspp, int u,
                                          int tid, int nthr, int Bs, int B) {
     const int K4 = f.K4;
     const int NT = Bs / 64, nt = (B + 63) / 64;
-    const int NT32 = Bs / 32, nt32 = (B + 31) / 32;
+    const int NT16 = Bs / 16, nt16 = (B + 15) / 16;
     // S1, S2: the per-tile partials are spread over the threads (one load each, then a fixed-order
     // tree) instead of every thread walking all of them in batches
     __shared__ double fin_red[2][4];
     double S1 = 0, S2 = 0;
-    for (int t = tid; t < nt32; t += nthr) {
-        const float2 pv = *reinterpret_cast<const float2*>(&f.S12p[((size_t)u * NT32 + t) * 2]);
+    for (int t = tid; t < f.NG * nt16; t += nthr) {      // (w-tile group, 16-sequence tile) partials
+        const int grp = t / nt16, tl = t - grp * nt16;
+        const float2 pv = *reinterpret_cast<const float2*>(&f.S12p[(((size_t)u * f.NG + grp) * NT16 + tl) * 2]);
         S1 += (double)pv.x; S2 += (double)pv.y;
     }
     S1 = wave_sum_d(S1); S2 = wave_sum_d(S2);
@@ -560,7 +563,7 @@ __global__ __launch_bounds__(128) void fin_bwd_kernel(const fin_args fin,
 int launch_fin_bwd(explainn_ctx* c, const explainn_params* p, const explainn_grads* g, int B,
                    int freeze_n, hipStream_t s) {
     const fin_args fin = {c->S12p, c->m, c->Gw, c->mug, c->sig1, p->bn1_w, g->conv_w, g->conv_b,
-                          g->bn1_w, g->bn1_b, c->K4, freeze_n};
+                          g->bn1_w, g->bn1_b, c->K4, freeze_n, fc_ng(c->NQ)};
     hipLaunchKernelGGL(fin_bwd_kernel, dim3(c->U), dim3(128), 0, s, fin, c->Dspp, c->Bs, B);
     LAUNCH_CHECK();
     return EXPLAINN_OK;

@@ -58,7 +58,7 @@ struct explainn_ctx {
     double* qbar;         // [U][NS]
     float* VC;            // [U][100][NS]     V1 . C  (BN2 variance in prep2, BN2 backward in mid)
     float* A2;            // [U][100][NS]     FC1 weights with BN2 folded in
-    float* A2f;           // [U][4][NKS][64]  the same in MFMA A-fragment order (fc_fwd stages it)
+    float* A2f;           // [U][7][NK4Q][64][4] the same in MFMA 16x16x4 A-fragment order (fc_fwd stages it)
     float* sh2;           // [U][100]
     float* sig2;          // [U][100]
     float* z;             // [U][Bs]          FC2 output (without its bias)
@@ -71,12 +71,12 @@ struct explainn_ctx {
     float* Sep;           // [U][ACH][100]
     float* EQs;           // [U][100][NS]
     float* Tt;            // [U][100][NS]
-    float* Ttf;           // [U][NWT][50][64]  T in MFMA A-fragment order (passB copies it to LDS)
-    float* Mff;           // [U][NWT][NKS][64] M in MFMA A-fragment order
+    float* Ttf;           // [U][NW16][25][64]     T in MFMA 16x16x4 A-fragment order (passB copies it to LDS)
+    float* Mff;           // [U][NW16][4 NW16][64] M in A-fragment order, k order (j',i') -> v = 16j'+4g+i' 
     float* M;             // [U][NS][NS]
     float* k0p;           // [U][NS]
     float* dy;            // [U4][n][Bs]
-    float* S12p;          // [U][Bs/32][2]    per 32-sequence tile: sum dy, sum dy*chat
+    float* S12p;          // [U][NG][Bs/16][2] per (w-tile group, 16-sequence tile): sum dy, sum dy*chat
     float* Dspp;          // [U][Bs/64][4k]
     float* dlogits;       // [maxB][T]         (train_step only)
     float* dlT;           // [T][Bs]   d loss / d logits, task-major (head GEMMs, T > HEAD_GEMM_MIN_T)
@@ -274,6 +274,15 @@ static inline int nq_bucket(int n) {
         if (b[i] >= n) return b[i];
     return 0;
 }
+// ---- tiling of the FC kernels (fc.hip) on v_mfma_f32_16x16x4_f32 ----
+#define FC_MT 7                                          // 16-channel tiles covering the 100 hidden channels
+__host__ __device__ constexpr int fc_nk4(int NQ) { return (NQ + 3) / 4; }      // k-steps over pooled positions
+__host__ __device__ constexpr int fc_nk4q(int NQ) { return (fc_nk4(NQ) + 3) / 4; }  // ... in float4 groups of 4
+__host__ __device__ constexpr int fc_nw16(int NQ) { return (NQ + 15) / 16; }   // 16-wide tiles of pooled positions
+// passA / passB split the w tiles into groups of WGT (one wave / workgroup per group)
+__host__ __device__ constexpr int fc_wgt(int NQ) { return fc_nw16(NQ) <= 2 ? fc_nw16(NQ) : 3; }
+__host__ __device__ constexpr int fc_ng(int NQ) { return (fc_nw16(NQ) + fc_wgt(NQ) - 1) / fc_wgt(NQ); }
+
 #define NQ_DISPATCH(NQv, CALL)                                                        \
     switch (NQv) {                                                                    \
         case 4: { CALL(4); } break;     case 8: { CALL(8); } break;                   \

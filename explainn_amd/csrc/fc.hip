@@ -232,7 +232,7 @@ int launch_fc_fwd(explainn_ctx* c, const explainn_params* p, int B, bool train,
 // stride 68 makes the operand reads conflict-free: bank = (4 row + column) mod 64 with 16 rows x 4
 // columns per read.
 // ---------------------------------------------------------------------------------------------
-#define QT_LD 68
+#define QA_LD 66
 template <int NQ>
 __global__ __launch_bounds__(64) void passA_kernel(const float* __restrict__ ext,
                                                    const float* __restrict__ alpha,
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(64) void passA_kernel(const float* __restrict__ ext
                                                    float* __restrict__ Sep, int n, int Bs, int B,
                                                    int ACH) {
     constexpr int NS = ns_stride(NQ), NW16 = fc_nw16(NQ), WGT = fc_wgt(NQ), ROWS = 16 * WGT;
-    __shared__ float tq[ROWS * QT_LD];
+    __shared__ float tq[ROWS * QA_LD];
     __shared__ __attribute__((aligned(16))) uint4 tw[64];
     __shared__ float tdz[64];
     const int u = blockIdx.y, ch = blockIdx.x, grp = blockIdx.z, lane = threadIdx.x;
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(64) void passA_kernel(const float* __restrict__ ext
     if (bbeg < bend) fetch(bbeg);
     for (int b0 = bbeg; b0 < bend; b0 += 64) {
 #pragma unroll
-        for (int i = 0; i < ROWS; ++i) tq[i * QT_LD + lane] = rq[i];
+        for (int i = 0; i < ROWS; ++i) tq[i * QA_LD + lane] = rq[i];
         tw[lane] = rw;
         tdz[lane] = rdz;
         if (b0 == bbeg) STAMP(1);
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(64) void passA_kernel(const float* __restrict__ ext
             const int col = 4 * s + g;
             float qv[WGT];
 #pragma unroll
-            for (int j = 0; j < WGT; ++j) qv[j] = tq[(16 * j + c) * QT_LD + col];
+            for (int j = 0; j < WGT; ++j) qv[j] = tq[(16 * j + c) * QA_LD + col];
             const float dzb = tdz[col];
             const uint4 wv = tw[col];
             // bit of channel r = 16t + c: word t>>1, bit 16(t&1) + c -> shift by c once per word

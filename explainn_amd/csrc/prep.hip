@@ -392,7 +392,7 @@ __global__ __launch_bounds__(1024) void prep2_kernel(
     float* __restrict__ rv2, int64_t* nbt, const float* __restrict__ qs0,
     const float* __restrict__ S1p, const float* __restrict__ S2p, double* __restrict__ qbar,
     float* __restrict__ VC, float* __restrict__ A2, float* __restrict__ A2f,
-    float* __restrict__ sh2, float* __restrict__ sig2, int n, int NS, int NKS, int B, int QCH) {
+    float* __restrict__ sh2, float* __restrict__ sig2, int n, int NS, int NK4Q, int B, int QCH) {
     extern __shared__ double sm[];            // qb[NS] (double) | Cs[n][n] | V1s[100][n+1]
     const int u = blockIdx.x, tid = threadIdx.x;
     constexpr int NT = 1024;
@@ -548,16 +548,16 @@ __global__ __launch_bounds__(1024) void prep2_kernel(
         if (u == 0 && tid == 0 && nbt) *nbt += 1;
         STAMP(2);
     }
-    // the same weights in MFMA A-fragment order for fc_fwd:
-    // A2f[((t*NKS + s)*64) + l] = A2[32t + (l&31)][2s + (l>>5)]
+    // the same weights in MFMA 16x16x4 A-fragment order for fc_fwd, four k-steps per float4:
+    // A2f[(((t*NK4Q + sq)*64 + l)*4 + e] = A2[16t + (l&15)][4*(4sq+e) + (l>>4)]
     __syncthreads();
     const float* a2lds = TRAIN ? reinterpret_cast<const float*>(sm + NS) + n * n : nullptr;   // = V1s
-    for (int i = tid; i < 4 * NKS * 64; i += NT) {
-        const int l = i & 63, s = (i >> 6) % NKS, t = (i >> 6) / NKS;
-        const int r = 32 * t + (l & 31), w = 2 * s + (l >> 5);
+    for (int i = tid; i < FC_MT * NK4Q * 256; i += NT) {
+        const int e = i & 3, l = (i >> 2) & 63, sq = (i >> 8) % NK4Q, t = (i >> 8) / NK4Q;
+        const int r = 16 * t + (l & 15), w = 4 * (4 * sq + e) + (l >> 4);
         float v = 0.f;
         if (r < FC_H && w < n) v = TRAIN ? a2lds[r * (n + 1) + w] : A2[((size_t)u * FC_H + r) * NS + w];
-        A2f[(size_t)u * 4 * NKS * 64 + i] = v;
+        A2f[(size_t)u * FC_MT * NK4Q * 256 + i] = v;
     }
     STAMP(3);
 }
@@ -567,12 +567,12 @@ int launch_prep2(explainn_ctx* c, const explainn_params* p, int B, bool train, h
         hipLaunchKernelGGL(prep2_kernel<true>, dim3(c->U), dim3(1024), prep2_lds(c->n, c->NS), s,
                            p->fc1_w, p->fc1_b, p->bn2_w, p->bn2_b, p->bn2_rm, p->bn2_rv, p->bn2_nbt,
                            c->qs0, c->qS1p, c->qS2p, c->qbar, c->VC, c->A2, c->A2f, c->sh2, c->sig2,
-                           c->n, c->NS, (c->NQ + 1) / 2, B, c->QCH);
+                           c->n, c->NS, fc_nk4q(c->NQ), B, c->QCH);
     else
         hipLaunchKernelGGL(prep2_kernel<false>, dim3(c->U), dim3(1024), 0, s, p->fc1_w, p->fc1_b,
                            p->bn2_w, p->bn2_b, p->bn2_rm, p->bn2_rv, (int64_t*)nullptr, c->qs0,
                            c->qS1p, c->qS2p, c->qbar, c->VC, c->A2, c->A2f, c->sh2, c->sig2, c->n,
-                           c->NS, (c->NQ + 1) / 2, B, c->QCH);
+                           c->NS, fc_nk4q(c->NQ), B, c->QCH);
     LAUNCH_CHECK();
     return EXPLAINN_OK;
 }
