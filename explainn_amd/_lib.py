@@ -51,7 +51,7 @@ EXPORTS = (
 
 
 class Params(C.Structure):
-    _fields_ = [(f, _fp) for f in PARAM_FIELDS]
+    _fields_ = [(f, _fp) for f in PARAM_FIELDS] + [("version", C.c_uint64)]
 
 
 class Grads(C.Structure):

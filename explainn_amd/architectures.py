@@ -240,7 +240,7 @@ class ExplaiNN(_Model):
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for key, val in self.__dict__.items():
-            if key in ("_slots", "_ps_cache"):        # resolved against THIS object's modules
+            if key in ("_slots", "_ps_cache", "_vkey", "_bufs"):   # resolved against THIS object's modules
                 continue
             new.__dict__[key] = _Runtime() if key == "_rt" else copy.deepcopy(val, memo)
         new.linears._bind(new)
@@ -248,7 +248,8 @@ class ExplaiNN(_Model):
 
     def __getstate__(self):
         state = self.__dict__.copy()
-        state.pop("_slots", None); state.pop("_ps_cache", None)      # ctypes tables: rebuilt on demand
+        for key in ("_slots", "_ps_cache", "_vkey", "_bufs"):     # ctypes tables: rebuilt on demand
+            state.pop(key, None)
         return state
 
     def __setstate__(self, state):
@@ -321,6 +322,7 @@ class ExplaiNN(_Model):
                 if cur is not t or cur.data_ptr() != ptr:
                     break
             else:
+                self._stamp_version(ps, keep)
                 return ps, keep
         ps = _lib.Params()
         keep, ptrs = [], []
@@ -335,7 +337,26 @@ class ExplaiNN(_Model):
             ptrs.append(t.data_ptr())
             setattr(ps, field, ptrs[-1])
         self.__dict__["_ps_cache"] = (dev, ps, keep, ptrs)
+        self.__dict__["_bufs"] = [t for (field, _, _, _), t in zip(slots, keep)
+                                  if field.endswith(("_rm", "_rv", "_nbt"))]
+        self.__dict__.pop("_vkey", None)
+        self._stamp_version(ps, keep)
         return ps, keep
+
+    def _stamp_version(self, ps, keep):
+        """explainn_params.version: a counter that moves whenever any of the 23 tensors changed
+        value (torch's per-tensor version counters; this package's own kernels, which write
+        through raw pointers, bump them explicitly -- _touched()).  The eval entry points rebuild
+        their folded tables only when it moved."""
+        vkey = tuple(t._version for t in keep)
+        if vkey != self.__dict__.get("_vkey"):
+            self.__dict__["_vkey"] = vkey
+            self.__dict__["_pver"] = self.__dict__.get("_pver", 0) + 1
+        ps.version = self.__dict__["_pver"]
+
+    def _touched(self):
+        """The train-mode kernels updated the BatchNorm buffers in place (as torch does)."""
+        torch.autograd.graph.increment_version(self.__dict__.get("_bufs") or list(self.buffers()))
 
     def _prep_input(self, x, dev):
         o = self._options
@@ -434,6 +455,7 @@ class ExplaiNN(_Model):
                 ctx.handle, self._x_ptr(ctx, x, dev), B, C.byref(ps), mask_ptr, float(self.dropout_p),
                 C.c_uint64(seed), logits.data_ptr(), self._stream(dev)))
             self._check_flags(ctx, dev)
+        self._touched()
         self._rt.token += 1
         return logits, self._rt.token
 

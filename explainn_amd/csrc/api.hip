@@ -107,8 +107,16 @@ int eval_front(explainn_ctx* c, const float* x, int B, const explainn_params* p,
     // with E_STATE instead of returning the eval batch's gradients
     c->fwd_B = 0; c->tail_B = 0;
     TRY(launch_pack(c, x, B, false, s));
-    TRY(launch_prep1_tables(c, p, s));
-    TRY(launch_prep1(c, p, B, false, s));
+    // The folded tables depend on the parameters only: rebuilt when the caller's parameter version
+    // moved (or is unknown), not per batch -- predict.py's loop and a validation pass run pack +
+    // filter bank + FC + head per batch and nothing else.
+    if (!(c->eval_valid && p->version != 0 && p->version == c->eval_version)) {
+        TRY(launch_prep1_tables(c, p, s));
+        TRY(launch_prep1(c, p, B, false, s));
+        TRY(launch_prep2(c, p, B, false, s));
+        c->eval_valid = true;
+        c->eval_version = p->version;
+    }
     return EXPLAINN_OK;
 }
 }  // namespace
@@ -224,7 +232,6 @@ extern "C" int explainn_forward_eval(explainn_ctx* c, const float* x, int B,
     hipStream_t s = static_cast<hipStream_t>(stream);
     TRY(eval_front(c, x, B, p, s));
     TRY(launch_conv_pool(c, p, B, s));
-    TRY(launch_prep2(c, p, B, false, s));
     TRY(launch_fc_fwd(c, p, B, false, nullptr, 0.f, 0, s));
     TRY(launch_head_fwd(c, p, B, false, logits, nullptr, s));
     return EXPLAINN_OK;
@@ -236,7 +243,6 @@ extern "C" int explainn_unit_outputs(explainn_ctx* c, const float* x, int B,
     hipStream_t s = static_cast<hipStream_t>(stream);
     TRY(eval_front(c, x, B, p, s));
     TRY(launch_conv_pool(c, p, B, s));
-    TRY(launch_prep2(c, p, B, false, s));
     TRY(launch_fc_fwd(c, p, B, false, nullptr, 0.f, 0, s));
     TRY(launch_head_fwd(c, p, B, false, nullptr, outs, s));
     return EXPLAINN_OK;
@@ -299,6 +305,7 @@ extern "C" int explainn_forward_train(explainn_ctx* c, const float* x, int B,
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     c->fwd_B = 0;
+    c->eval_valid = false;             // the train-mode folds overwrite the eval-mode tables
     // the one-hot batch is packed and the filter tables are built by one launch; a staged batch of
     // base codes (x == NULL) is already packed and only needs the tables
     if (x) TRY(launch_pack_tables(c, x, p, B, s));

@@ -13,6 +13,10 @@
 #include "common.h"
 
 typedef float f32x16b __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4b __attribute__((ext_vector_type(4)));
+#define CB_TILES 2           // 64-sequence tiles per conv_bwd wavefront
+#define CB_PF 4              // pooling windows whose dy / idx a conv_bwd lane fetches per batch
 
 // Register budget: this kernel must stay at <= 64 VGPRs so that TWO 1024-thread blocks share a CU --
 // 300 units on 256 CUs otherwise take two rounds.  (Batching the per-channel partial-sum loads below
@@ -360,7 +364,7 @@ struct fin_args {
 __device__ __forceinline__ void fin_unit(const fin_args& f, const float* __restrict__ Dspp, int u,
                                          int tid, int nthr, int Bs, int B) {
     const int K4 = f.K4;
-    const int NT = Bs / 64, nt = (B + 63) / 64;
+    const int NT = Bs / 64, nt = ((B + 63) / 64 + CB_TILES - 1) / CB_TILES;   // conv_bwd partials
     const int NT16 = Bs / 16, nt16 = (B + 15) / 16;
     // S1, S2: the per-tile partials are spread over the threads (one load each, then a fixed-order
     // tree) instead of every thread walking all of them in batches
@@ -399,44 +403,61 @@ __device__ __forceinline__ void fin_unit(const fin_args& f, const float* __restr
 }
 
 template <int K>
-__global__ __launch_bounds__(64, 5) void conv_bwd_kernel(const float* __restrict__ dy,
+__global__ __launch_bounds__(64, (K <= 24 ? 4 : 3)) void conv_bwd_kernel(const float* __restrict__ dy,
                                                          const uint8_t* __restrict__ idx,
                                                          const uint32_t* __restrict__ pk2,
                                                          const uint32_t* __restrict__ nmask,
                                                          float* __restrict__ Dspp, int U, int n,
                                                          int Bs, int PW, int NW, int nlds_off,
                                                          int B) {
-    // One wavefront = 64 sequences x one unit; lane = sequence.  The partial sums of a lane live in
-    // REGISTERS: per tap three compare-select-adds for bases C,G,T; base A is recovered at the end
-    // as (sum of all dy) - C - G - T.  N positions are packed as 'C'; the lanes that have one also add
-    // that dy to a per-tap LDS cell, which is taken out of C at the end.  No LDS traffic in the loop (LDS float atomics
+    // One wavefront = CB_TILES x 64 sequences x one unit; lane = sequence.  The partial sums of a lane
+    // live in REGISTERS: per tap the sums for bases C,G,T; base A is recovered at the end as
+    // (sum of all dy) - C - G - T.  N positions are packed as 'C'; the lanes that have one also add
+    // that dy to a per-tap LDS cell, which is taken out of C at the end.  (LDS float atomics
     // serialise per lane on gfx950 and LDS read-modify-write chains were latency-bound,
-    // profiles/r01_c); <= 102 VGPRs and 7 KB of LDS keep 5 waves per SIMD, i.e. the whole grid
-    // resident in one round at C2.
+    // profiles/r01_c.)  110 VGPRs = 4 waves per SIMD; two sequence tiles per wave keep the whole
+    // grid (2400 waves at C2) resident in one round.
     // The packed codes are staged per chunk of CBW pooling windows (the positions a chunk touches
     // span CBW*7 + K - 1 bases): a fixed ~7 KB of LDS per wave whatever the sequence length, so the
     // 5 waves/SIMD hold for L = 1000 too (staging the whole sequence cost 26 KB there and left
     // 1.5 waves/SIMD).  Columns are lane-private: no barrier between chunks.
     constexpr int CBW = 32;
     constexpr int PWC = ((POOLW * CBW + K + 15) >> 4) + 2, NWC = ((POOLW * CBW + K + 31) >> 5) + 2;
-    extern __shared__ uint32_t smem[];        // pk2 chunk [PWC][64], nmask chunk [NWC][64]
-    uint32_t* pks = smem;
-    uint32_t* nms = smem + (size_t)PWC * 64;
-    const int lane = threadIdx.x, tile = blockIdx.x, u = blockIdx.y;
-    const int b = tile * 64 + lane;
+    extern __shared__ uint32_t smem[];        // one-hot rows [4] float4, pk2 chunk [PWC][64], nmask chunk [NWC][64]
+    uint32_t* pks = smem + 16;
+    uint32_t* nms = pks + (size_t)PWC * 64;
+    const int lane = threadIdx.x, u = blockIdx.y;
     STAMP(0);
     constexpr uint32_t KMASK = (K >= 32) ? 0xffffffffu : ((1u << K) - 1u);
-    float a1[K], a2[K], a3[K];
+    // One-hot rows {c==A, c==C, c==G, c==T} per 2-bit code as floats: acc[j] += dy * row[code_j] is
+    // one ds_read_b128 (4 distinct addresses per wave: broadcast, no conflicts), one v_pk_fma_f32
+    // (C, G) and one v_fma_f32 (T) per tap; A = total - C - G - T at the end.  (Three compare-select-add triples per tap were 10 VALU instructions
+    // per tap and made this kernel the VALU-issue-bound maximum of the step, profiles/r01_final.)
+    f32x2 a12[K];
+    float a3[K];
+    float tot = 0.f;
 #pragma unroll
-    for (int j = 0; j < K; ++j) { a1[j] = 0.f; a2[j] = 0.f; a3[j] = 0.f; }
+    for (int j = 0; j < K; ++j) { a12[j] = f32x2{0.f, 0.f}; a3[j] = 0.f; }
     // dy that landed in the C bucket because an N base is packed as 'C', per tap: one LDS float per
     // tap, fed by the few lanes that have an N (one wavefront per block, so the order of the adds
     // -- lane order, instruction order -- is fixed and the sum reproducible)
     float* nlds = reinterpret_cast<float*>(smem) + nlds_off;
+    // the one-hot rows sit at the very start of the dynamic LDS, so that a row's address is the
+    // code field itself (no base add): row c = {c==C, c==G, c==T, 0}
+    float4* oh = reinterpret_cast<float4*>(smem);
     if (lane < K) nlds[lane] = 0.f;
-    float tot = 0.f;
+    if (lane < 4) oh[lane] = make_float4(lane == 1 ? 1.f : 0.f, lane == 2 ? 1.f : 0.f, lane == 3 ? 1.f : 0.f, 0.f);
+    __syncthreads();
+    typedef __attribute__((address_space(3))) f32x4b lds_f32x4;
+    typedef __attribute__((address_space(3))) char lds_char;
+    // 32-bit LDS address of the rows (64-byte aligned: the code field is OR-ed in, one v_and_or_b32)
+    const uint32_t ohbase = (uint32_t)(size_t)(const lds_char*)(reinterpret_cast<const char*>(oh));
     const float* __restrict__ dyu = dy + (size_t)u * n * Bs;
     const uint8_t* __restrict__ idxu = idx + (size_t)u * n * Bs;
+    for (int tl = 0; tl < CB_TILES; ++tl) {
+    const int tile = blockIdx.x * CB_TILES + tl;
+    if (tile * 64 >= B) break;                         // wave-uniform
+    const int b = tile * 64 + lane;
     for (int wc = 0; wc < n; wc += CBW) {
         // chunk origin in words: POOLW*CBW = 224 positions = 14 code words = 7 mask words
         const int w_lo = (POOLW * wc) >> 4, n_lo = (POOLW * wc) >> 5;
@@ -444,65 +465,97 @@ __global__ __launch_bounds__(64, 5) void conv_bwd_kernel(const float* __restrict
                                  nms + lane, nmask + (size_t)n_lo * Bs + b, min(NWC, NW - n_lo), Bs);
         if (wc == 0) STAMP(1);
         const int wend = min(wc + CBW, n);
-        // dy / idx for two windows are requested together (more would cost the 5th wave per SIMD)
-        for (int wb = wc; wb < wend; wb += 2) {
-            float dyq[2];
-            int psq[2];
+        // dy / idx are fetched CB_PF windows at a time, one batch ahead of the taps that consume them:
+        // with a single window in flight every event waited out a full L2 round trip (49 us of
+        // latency for 25 us of issue, profiles/r02)
+        float dy_n[CB_PF];
+        int ps_n[CB_PF];
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int off = min(wb + q, wend - 1) * Bs + b;   // 32-bit lane offset, uniform base
-                dyq[q] = dyu[off];                         // unconditional (w is clamped)
-                psq[q] = (int)idxu[off];
-            }
+        for (int q = 0; q < CB_PF; ++q) {
+            const int off = min(wc + q, wend - 1) * Bs + b;       // 32-bit lane offset, uniform base
+            dy_n[q] = dyu[off];
+            ps_n[q] = (int)idxu[off];
+        }
+        for (int wb0 = wc; wb0 < wend; wb0 += CB_PF) {
+        float dy_c[CB_PF];
+        int ps_c[CB_PF];
 #pragma unroll
-            for (int q = 0; q < 2; ++q) { KEEP(dyq[q]); KEEP(psq[q]); }
+        for (int q = 0; q < CB_PF; ++q) { KEEP(dy_n[q]); KEEP(ps_n[q]); dy_c[q] = dy_n[q]; ps_c[q] = ps_n[q]; }
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                // lanes past the batch (the last, partly filled tile) must not contribute: their dy
-                // is whatever an earlier, larger batch left there
-                dyq[q] = (wb + q < wend && b < B) ? dyq[q] : 0.f;
-                psq[q] += POOLW * min(wb + q, wend - 1);
-            }
+        for (int q = 0; q < CB_PF; ++q) {
+            const int off = min(wb0 + CB_PF + q, wend - 1) * Bs + b;
+            dy_n[q] = dyu[off];
+            ps_n[q] = (int)idxu[off];
+        }
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const float dyv = dyq[q];                  // 0 for windows past the end
-                const int ps = psq[q];
-                const int w0 = (ps >> 4) - w_lo, sh = (ps & 15) * 2;
-                const uint32_t c0 = pks[w0 * 64 + lane], c1 = pks[(w0 + 1) * 64 + lane],
-                               c2 = pks[(w0 + 2) * 64 + lane];
-                const uint32_t lo = __funnelshift_r(c0, c1, sh), hi = __funnelshift_r(c1, c2, sh);
-                const int n0 = (ps >> 5) - n_lo, nsh = ps & 31;
-                const uint32_t nm = __funnelshift_r(nms[n0 * 64 + lane], nms[(n0 + 1) * 64 + lane], nsh) & KMASK;
+        for (int q = 0; q < CB_PF; ++q) {
+            const int wb = wb0 + q;
+            float dyv = (wb < wend) ? dy_c[q] : 0.f;
+            const int ps = ps_c[q] + POOLW * min(wb, wend - 1);
+            // lanes past the batch (the last, partly filled tile) must not contribute: their dy is
+            // whatever an earlier, larger batch left there
+            dyv = (b < B) ? dyv : 0.f;
+            const int w0 = (ps >> 4) - w_lo, sh = (ps & 15) * 2;
+            const uint32_t c0 = pks[w0 * 64 + lane], c1 = pks[(w0 + 1) * 64 + lane],
+                           c2 = pks[(w0 + 2) * 64 + lane];
+            const uint32_t lo = __funnelshift_r(c0, c1, sh), hi = __funnelshift_r(c1, c2, sh);
+            const int n0 = (ps >> 5) - n_lo, nsh = ps & 31;
+            uint32_t nm = __funnelshift_r(nms[n0 * 64 + lane], nms[(n0 + 1) * 64 + lane], nsh) & KMASK;
+            const f32x2 dy2 = f32x2{dyv, dyv};
+            // rows are fetched five at a time and consumed at once: all K in flight would need 4K
+            // registers
 #pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    const uint32_t code = (j < 16 ? (lo >> (2 * j)) : (hi >> (2 * (j - 16)))) & 3u;
-                    a1[j] += (code == 1u) ? dyv : 0.f;
-                    a2[j] += (code == 2u) ? dyv : 0.f;
-                    a3[j] += (code == 3u) ? dyv : 0.f;
-                }
-                uint32_t r = nm;
-                while (__any(r != 0u)) {
-                    if (r != 0u) {
-                        const int j = __ffs(r) - 1;
-                        r &= r - 1u;
-                        atomicAdd(&nlds[j], dyv);
+            for (int j0 = 0; j0 < K; j0 += 5) {
+                f32x4b r[5];
+#pragma unroll
+                for (int jj = 0; jj < 5; ++jj) {
+                    const int j = j0 + jj;
+                    if (j < K) {
+                        // byte offset of the code's one-hot row: code * 16
+                        const uint32_t off16 = j < 16 ? ((j >= 2 ? (lo >> (2 * j - 4)) : (lo << (4 - 2 * j))) & 0x30u)
+                                                      : ((j >= 18 ? (hi >> (2 * (j - 16) - 4)) : (hi << (4 - 2 * (j - 16)))) & 0x30u);
+                        // (volatile: the fourth component is unused and a narrowed ds_read_b96
+                        // costs twice the LDS cycles of the b128)
+                        r[jj] = *(const volatile lds_f32x4*)(size_t)(off16 | ohbase);
                     }
                 }
-                tot += dyv;
+#pragma unroll
+                for (int jj = 0; jj < 5; ++jj) {
+                    const int j = j0 + jj;
+                    if (j < K) {
+                        a12[j] = __builtin_elementwise_fma(dy2, f32x2{r[jj][0], r[jj][1]}, a12[j]);
+                        a3[j] = fmaf(dyv, r[jj][2], a3[j]);
+                        // pinned here: otherwise the sums sink below the N loop into the loop latch
+                        // and all K rows (4K registers) stay live across it
+                        KEEP(a12[j]); KEEP(a3[j]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            tot += dyv;
+            // N bases (packed as 'C'): the few lanes that have one add that dy to the tap's LDS cell
+            while (__any(nm != 0u)) {
+                if (nm != 0u) {
+                    const int j = __ffs(nm) - 1;
+                    nm &= nm - 1u;
+                    atomicAdd(&nlds[j], dyv);
+                }
             }
         }
+        }
+    }
     }
     STAMP(2);
     // sums over the 64 lanes through LDS, one base at a time: every lane parks K values as a column
     // of a [K][65] tile (the code tiles are dead by now), then lane j adds up row j
-    float* red = reinterpret_cast<float*>(smem);
-    float* out = Dspp + ((size_t)u * (Bs / 64) + tile) * 4 * K;
+    float* red = reinterpret_cast<float*>(smem) + 16;
+    float* out = Dspp + ((size_t)u * (Bs / 64) + blockIdx.x) * 4 * K;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            const float v = a == 0 ? (tot - a1[j] - a2[j] - a3[j]) : (a == 1 ? a1[j] : (a == 2 ? a2[j] : a3[j]));
+            const float v = a == 0 ? (tot - a12[j][0] - a12[j][1] - a3[j]) : (a == 1 ? a12[j][0] : (a == 2 ? a12[j][1] : a3[j]));
             red[j * 65 + lane] = v;
         }
         __syncthreads();
@@ -535,12 +588,13 @@ __global__ __launch_bounds__(64, 5) void conv_bwd_kernel(const float* __restrict
     }
 
 int launch_conv_bwd(explainn_ctx* c, int B, hipStream_t s) {
-    const dim3 grid((B + 63) / 64, c->U);
+    const dim3 grid(((B + 63) / 64 + CB_TILES - 1) / CB_TILES, c->U);
     // chunk tiles (see the kernel: [PWC + NWC][64] words) or the [k][65] reduction tile
     const int pwc = ((POOLW * 32 + c->k + 15) >> 4) + 2, nwc = ((POOLW * 32 + c->k + 31) >> 5) + 2;
     size_t sm = (size_t)(pwc + nwc) * 64 * sizeof(uint32_t);
     const size_t red_bytes = (size_t)c->k * 65 * sizeof(float);
     if (sm < red_bytes) sm = red_bytes;
+    sm += 4 * sizeof(float4);                          // the one-hot rows in front of the tiles
     const int nlds_off = (int)(sm / sizeof(float));    // k floats behind the tiles: the N corrections
     sm += (size_t)((c->k + 15) & ~15) * sizeof(float);
 #define CALL(KK)                                                                               \

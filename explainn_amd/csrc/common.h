@@ -92,6 +92,10 @@ struct explainn_ctx {
     unsigned char seen_key[512];
     int graph_key_len, seen_count;
     int staged_B;         // batch size of the codes explainn_stage_codes() staged, 0 = none
+    // eval-mode tables (filter tables, BatchNorm1/2 folds, FC1 fragments) held in the scratch are
+    // those of parameter version eval_version; a train-mode forward overwrites them
+    bool eval_valid;
+    uint64_t eval_version;
     int* flags;           // [1]
     int* site_cnt;        // [U4][Bs]  sites per (unit, sequence) of the current batch (filter->PWM export)
     int* site_off;        // [U4][Bs]  their exclusive scan in sequence order, plus the running total

@@ -89,5 +89,6 @@ class StepEngine:
                 self.ctx.handle, B, C.byref(self.ps), C.byref(self.gs), int(freeze_top_n_filters),
                 stream))
             grad_sync.finish(work)
+        m._touched()
         m._rt.token += 1
         return self.logits[:B], self.loss

@@ -118,6 +118,9 @@ class FusedAdam(torch.optim.Adam):
                         plan["n"], plan["p_arr"], plan["g_arr"], plan["m_arr"], plan["v_arr"],
                         plan["sizes"], plan["count"], float(group["lr"]), float(beta1),
                         float(beta2), float(group["eps"]), stream))
+                    # the kernel wrote through raw pointers: move torch's version counters as an
+                    # in-place torch update would (the model's eval-table cache keys on them)
+                    torch.autograd.graph.increment_version(plan["params"])
                 else:
                     # parameters added later carry their own step count: one launch per tensor
                     for i in range(plan["n"]):
@@ -127,6 +130,7 @@ class FusedAdam(torch.optim.Adam):
                             one(plan["v_arr"]), (C.c_int64 * 1)(plan["sizes"][i]),
                             int(plan["steps"][i].item()), float(group["lr"]), float(beta1),
                             float(beta2), float(group["eps"]), stream))
+                    torch.autograd.graph.increment_version(plan["params"])
         return loss
 
     def load_state_dict(self, state_dict):

@@ -167,7 +167,9 @@ class Trainer(object):
             if self.step % 64 == 1 or getattr(self, "_w0_ptr", None) != w0.data_ptr():
                 eng.refresh_params()
                 self._w0_ptr = w0.data_ptr()
-            _, loss = eng.step(inputs.float().contiguous(), targets.float().contiguous(),
+            if inputs.dtype != torch.uint8:           # base codes (loader.CodesLoader) go in as they are
+                inputs = inputs.float()
+            _, loss = eng.step(inputs.contiguous(), targets.float().contiguous(),
                                seed=int(torch.randint(0, 2 ** 62, (1,)).item()),
                                freeze_top_n_filters=self.freeze_top_n_filters)
             if self._grad_sync is not None:

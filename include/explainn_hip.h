@@ -63,6 +63,12 @@ typedef struct explainn_params {
     int64_t* bn1_nbt;      /* linears.1.num_batches_tracked  () int64, may be NULL        */
     int64_t* bn2_nbt;      /* linears.7.num_batches_tracked                               */
     int64_t* bn3_nbt;      /* linears.11.num_batches_tracked                              */
+    /* Version of the VALUES behind the pointers above, maintained by the caller: bump it whenever
+     * a parameter or running statistic changes (the Python binding derives it from torch's tensor
+     * version counters).  Eval-mode entry points keep the folded BatchNorm / filter tables of the
+     * last version they saw and rebuild them only when it differs.  0 = unknown: rebuild on
+     * every call (what a zero-initialised struct gets). */
+    uint64_t version;
 } explainn_params;
 
 /* Gradient outputs, same shapes as the parameters; every array is OVERWRITTEN (not

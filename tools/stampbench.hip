@@ -33,21 +33,21 @@ static void report(const char* name, int waves, int nst, float ms) {
 }
 
 int main() {
-    const int U = 300, n = 26, B = 1024, Bs = 1088, NQ = 26, NS = ns_stride(NQ), NKS = 13, QCH = 8, ACH = 8;
+    const int U = 300, n = 26, B = 1024, Bs = 1088, NQ = 26, NS = ns_stride(NQ), NKS = 13, QCH = 8, ACH = 8, NK4Q = fc_nk4q(NQ), NW16 = fc_nw16(NQ);
     auto dalloc = [](size_t bytes) { void* p; CK(hipMalloc(&p, bytes)); CK(hipMemset(p, 0, bytes)); return p; };
     float* ext = (float*)dalloc((size_t)U * n * Bs * 4); float* alpha = (float*)dalloc(U * 4); float* shift = (float*)dalloc(U * 4);
     std::vector<float> he((size_t)U * n * Bs); for (auto& v : he) v = (rand() % 2000) * 1e-3f - 1.f;
     CK(hipMemcpy(ext, he.data(), he.size() * 4, hipMemcpyHostToDevice));
     std::vector<float> ha(U, 0.7f); CK(hipMemcpy(alpha, ha.data(), U * 4, hipMemcpyHostToDevice));
     float* qs0 = (float*)dalloc(U * NS * 4); float* S1p = (float*)dalloc((size_t)U * QCH * NS * 4); float* S2p = (float*)dalloc((size_t)U * QCH * NS * NS * 4);
-    float* A2f = (float*)dalloc((size_t)U * 4 * NKS * 64 * 4); float* sh2 = (float*)dalloc(U * 100 * 4); float* V2 = (float*)dalloc(U * 100 * 4);
-    std::vector<float> hw((size_t)U * 4 * NKS * 64); for (auto& v : hw) v = (rand() % 2000) * 1e-3f - 1.f;
+    float* A2f = (float*)dalloc((size_t)U * FC_MT * NK4Q * 256 * 4); float* sh2 = (float*)dalloc(U * 100 * 4); float* V2 = (float*)dalloc(U * 100 * 4);
+    std::vector<float> hw((size_t)U * FC_MT * NK4Q * 256); for (auto& v : hw) v = (rand() % 2000) * 1e-3f - 1.f;
     CK(hipMemcpy(A2f, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
     uint4* bits = (uint4*)dalloc((size_t)U * Bs * 16 + 64); float* z = (float*)dalloc((size_t)U * Bs * 4); float* o = (float*)dalloc((size_t)U * Bs * 4);
     float* dz = (float*)dalloc((size_t)U * Bs * 4 + 64); float* EQp = (float*)dalloc((size_t)U * ACH * 100 * NS * 4); float* Sep = (float*)dalloc((size_t)U * ACH * 100 * 4);
     float* Tt = (float*)dalloc((size_t)(U * 100 + 2) * NS * 8); float* M = (float*)dalloc((size_t)(U * NS + 2) * NS * 8); float* k0p = (float*)dalloc(U * NS * 4);
     double* mug = (double*)dalloc(U * 8); double* sig1 = (double*)dalloc(U * 8); std::vector<double> one(U, 1.0); CK(hipMemcpy(sig1, one.data(), U * 8, hipMemcpyHostToDevice));
-    float* dy = (float*)dalloc((size_t)U * n * Bs * 4); float* S12p = (float*)dalloc((size_t)U * (Bs / 32) * 2 * 4);
+    float* dy = (float*)dalloc((size_t)U * n * Bs * 4); float* S12p = (float*)dalloc((size_t)U * (Bs / 16) * 2 * 4);
     float* fz = (float*)dalloc(U * 4);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); float ms;
     for (int rep = 0; rep < 2; ++rep) {
@@ -57,7 +57,7 @@ int main() {
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
         if (rep) report("qmom", QCH * U, 4, ms);
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((fc_fwd_kernel<26, 2>), dim3(4, U), dim3(256), 0, 0, ext, alpha, shift, A2f, sh2, V2, bits, z, (const uint8_t*)nullptr, 19661u, 1.4285715f, 1u, 2u, fz, fz, fz, fz, fz, o, n, Bs, B, U, (const uint32_t*)nullptr);
+        hipLaunchKernelGGL((fc_fwd_kernel<26, 2>), dim3(4, U), dim3(256), fc_fwd_lds<26>(), 0, ext, alpha, shift, A2f, sh2, V2, bits, z, (const uint8_t*)nullptr, 19661u, 1.4285715f, 1u, 2u, fz, fz, fz, fz, fz, o, n, Bs, B, U, (const uint32_t*)nullptr);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
         if (rep) report("fc_fwd", 4 * U * 4, 5, ms);
         CK(hipEventRecord(e0));
@@ -65,7 +65,7 @@ int main() {
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
         if (rep) report("passA", ACH * U, 4, ms);
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(passB_kernel<26>, dim3(4, U), dim3(256), passB_lds<26>(), 0, ext, alpha, shift, dz, bits, Tt, M, k0p, mug, sig1, dy, S12p, n, Bs, B); // (tables passed as fragment-ordered stand-ins)
+        hipLaunchKernelGGL(passB_kernel<26>, dim3(4, U, 1), dim3(256), passB_lds<26>(), 0, ext, alpha, shift, dz, bits, Tt, M, k0p, mug, sig1, dy, S12p, n, Bs, B); // (tables passed as fragment-ordered stand-ins)
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
         if (rep) report("passB", 4 * U * 4, 6, ms);
     }
@@ -89,15 +89,15 @@ int main() {
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
             if (rep) report("conv_pool", 16 * 2 * (U4 / 2), 3, ms);
             CK(hipEventRecord(e0));
-            hipLaunchKernelGGL(conv_bwd_kernel<19>, dim3(16, U), dim3(64), (size_t)(PW + NW) * 256 + 128, 0, dy, idx, pk2, nmask, Dspp, U, n, Bs, PW, NW, (PW + NW) * 64, B);
+            hipLaunchKernelGGL(conv_bwd_kernel<19>, dim3(8, U), dim3(64), (size_t)(PW + NW) * 256 + 128 + 64, 0, dy, idx, pk2, nmask, Dspp, U, n, Bs, PW, NW, (PW + NW) * 64, B);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
-            if (rep) report("conv_bwd", 16 * U, 4, ms);
+            if (rep) report("conv_bwd", 8 * U, 4, ms);
             CK(hipEventRecord(e0));
-            hipLaunchKernelGGL(prep2_kernel<true>, dim3(U), dim3(1024), prep2_lds(n, NS), 0, fc1_w, sh2, sh2, sh2, md, md + U * 100, (int64_t*)nullptr, qs0, S1p, S2p, qbar, VC, A2, A2f, sh2, sig2, n, NS, NKS, B, QCH);
+            hipLaunchKernelGGL(prep2_kernel<true>, dim3(U), dim3(1024), prep2_lds(n, NS), 0, fc1_w, sh2, sh2, sh2, md, md + U * 100, (int64_t*)nullptr, qs0, S1p, S2p, qbar, VC, A2, A2f, sh2, sig2, n, NS, NK4Q, B, QCH);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
             if (rep) report("prep2", U * 16, 4, ms);
             CK(hipEventRecord(e0));
-            hipLaunchKernelGGL(mid_fused_kernel, dim3(U), dim3(1024), mid_fused_lds(n), 0, EQp, Sep, A2, sh2, sig2, fc1_w, V2, sh2, qbar, VC, Tt, Tt, M, M, k0p, md, md, md, md, md, n, NS, 1, 13, B, ACH, 1.4285715f);
+            hipLaunchKernelGGL(mid_fused_kernel, dim3(U), dim3(1024), mid_fused_lds(n), 0, EQp, Sep, A2, sh2, sig2, fc1_w, V2, sh2, qbar, VC, Tt, Tt, M, M, k0p, md, md, md, md, md, n, NS, NW16, B, ACH, 1.4285715f);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
             if (rep) report("mid_fused", U * 16, 6, ms);
         }
