@@ -38,7 +38,7 @@ void carve(explainn_ctx* c, Carver& cv) {
     cv.take(&c->codesT, (int64_t)c->L * Bs);
     cv.take(&c->pk2, (int64_t)c->PW * Bs);
     cv.take(&c->nmask, (int64_t)c->NW * Bs);
-    cv.take(&c->cnt, (int64_t)c->k * c->L * 16);
+    cv.take(&c->bm, (int64_t)4 * (Bs / 64) * c->Lp);
     cv.take(&c->G, K4 * K4);
     cv.take(&c->m, K4);
     cv.take(&c->alpha, U4);
@@ -159,6 +159,7 @@ extern "C" int explainn_create(explainn_ctx** out, int cnn_units, int kernel_siz
     c->Bs = (max_batch + 63) & ~63;
     if (((c->Bs / 64) & 1) == 0) c->Bs += 64;
     c->NW = (sequence_length + 31) / 32 + 2; c->PW = 2 * c->NW;
+    c->Lp = ((c->NW * 32 + 63) / 64) * 64;
     {
         int q = (max_batch + 127) / 128;
         const int64_t per = (int64_t)c->U * c->NS * c->NS * 4;
@@ -313,15 +314,24 @@ extern "C" int explainn_forward_train(explainn_ctx* c, const float* x, int B,
         TRY(launch_pack(c, x, B, false, s));
         TRY(launch_prep1_tables(c, p, s));
     }
-    // fork: the input-moment chain (pair counts -> Gram -> BatchNorm1 fold) needs only the packed
-    // codes, the filter bank only the filter tables and sign(gamma1): run them side by side
-    HIP_TRY(hipEventRecord(c->ev_fork, s));
-    HIP_TRY(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-    TRY(launch_moments(c, B, c->side));
-    TRY(launch_prep1(c, p, B, true, c->side));
-    HIP_TRY(hipEventRecord(c->ev_join, c->side));
-    TRY(launch_conv_pool(c, p, B, s));
-    HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
+    // The input-moment chain (bit masks -> Gram -> BatchNorm1 fold) needs only the packed codes, the
+    // filter bank only the filter tables and sign(gamma1).  Run in series they cost ~7 us before the
+    // filter bank; forked onto the side stream (EXPLAINN_FORK=1) they run beside it, but the filter
+    // bank fills every wave slot of the chip and the two stretch each other.
+    static const bool fork = [] { const char* e = getenv("EXPLAINN_FORK"); return e && e[0] == '1'; }();
+    if (fork) {
+        HIP_TRY(hipEventRecord(c->ev_fork, s));
+        HIP_TRY(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+        TRY(launch_moments(c, B, c->side));
+        TRY(launch_prep1(c, p, B, true, c->side));
+        HIP_TRY(hipEventRecord(c->ev_join, c->side));
+        TRY(launch_conv_pool(c, p, B, s));
+        HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
+    } else {
+        TRY(launch_moments(c, B, s));
+        TRY(launch_prep1(c, p, B, true, s));
+        TRY(launch_conv_pool(c, p, B, s));
+    }
     TRY(launch_qmoments(c, B, s));
     TRY(launch_prep2(c, p, B, true, s));
     TRY(launch_fc_fwd(c, p, B, true, keep_mask, dropout_p, seed, s));

@@ -403,7 +403,7 @@ __device__ __forceinline__ void fin_unit(const fin_args& f, const float* __restr
 }
 
 template <int K>
-__global__ __launch_bounds__(64, (K <= 24 ? 4 : 3)) void conv_bwd_kernel(const float* __restrict__ dy,
+__global__ __launch_bounds__(64, 3) void conv_bwd_kernel(const float* __restrict__ dy,
                                                          const uint8_t* __restrict__ idx,
                                                          const uint32_t* __restrict__ pk2,
                                                          const uint32_t* __restrict__ nmask,
@@ -415,8 +415,8 @@ __global__ __launch_bounds__(64, (K <= 24 ? 4 : 3)) void conv_bwd_kernel(const f
     // (sum of all dy) - C - G - T.  N positions are packed as 'C'; the lanes that have one also add
     // that dy to a per-tap LDS cell, which is taken out of C at the end.  (LDS float atomics
     // serialise per lane on gfx950 and LDS read-modify-write chains were latency-bound,
-    // profiles/r01_c.)  110 VGPRs = 4 waves per SIMD; two sequence tiles per wave keep the whole
-    // grid (2400 waves at C2) resident in one round.
+    // profiles/r01_c.)  Two sequence tiles per wave: 2400 waves at C2, all resident at 3 waves per SIMD,
+    // which leaves the registers for the row prefetch below.
     // The packed codes are staged per chunk of CBW pooling windows (the positions a chunk touches
     // span CBW*7 + K - 1 bases): a fixed ~7 KB of LDS per wave whatever the sequence length, so the
     // 5 waves/SIMD hold for L = 1000 too (staging the whole sequence cost 26 KB there and left
@@ -502,29 +502,37 @@ __global__ __launch_bounds__(64, (K <= 24 ? 4 : 3)) void conv_bwd_kernel(const f
             const int n0 = (ps >> 5) - n_lo, nsh = ps & 31;
             uint32_t nm = __funnelshift_r(nms[n0 * 64 + lane], nms[(n0 + 1) * 64 + lane], nsh) & KMASK;
             const f32x2 dy2 = f32x2{dyv, dyv};
-            // rows are fetched five at a time and consumed at once: all K in flight would need 4K
-            // registers
+            // rows are fetched five at a time, one group ahead of the sums that consume them (all K
+            // in flight would need 4K registers; one group at a time left the LDS latency exposed
+            // four times per window)
+            auto row_addr = [&](int j) -> uint32_t {
+                // byte offset of the code's one-hot row: code * 16
+                const uint32_t off16 = j < 16 ? ((j >= 2 ? (lo >> (2 * j - 4)) : (lo << (4 - 2 * j))) & 0x30u)
+                                              : ((j >= 18 ? (hi >> (2 * (j - 16) - 4)) : (hi << (4 - 2 * (j - 16)))) & 0x30u);
+                return off16 | ohbase;
+            };
+            constexpr int NGRP = (K + 4) / 5;
+            f32x4b r[2][5];
 #pragma unroll
-            for (int j0 = 0; j0 < K; j0 += 5) {
-                f32x4b r[5];
+            for (int jj = 0; jj < 5; ++jj)
+                if (jj < K) r[0][jj] = *(const volatile lds_f32x4*)(size_t)row_addr(jj);
 #pragma unroll
-                for (int jj = 0; jj < 5; ++jj) {
-                    const int j = j0 + jj;
-                    if (j < K) {
-                        // byte offset of the code's one-hot row: code * 16
-                        const uint32_t off16 = j < 16 ? ((j >= 2 ? (lo >> (2 * j - 4)) : (lo << (4 - 2 * j))) & 0x30u)
-                                                      : ((j >= 18 ? (hi >> (2 * (j - 16) - 4)) : (hi << (4 - 2 * (j - 16)))) & 0x30u);
-                        // (volatile: the fourth component is unused and a narrowed ds_read_b96
-                        // costs twice the LDS cycles of the b128)
-                        r[jj] = *(const volatile lds_f32x4*)(size_t)(off16 | ohbase);
-                    }
+            for (int gq = 0; gq < NGRP; ++gq) {
+                const int j0 = 5 * gq;
+                if (gq + 1 < NGRP) {
+#pragma unroll
+                    for (int jj = 0; jj < 5; ++jj)
+                        if (j0 + 5 + jj < K)
+                            // (volatile: the fourth component is unused and a narrowed ds_read_b96
+                            // costs twice the LDS cycles of the b128)
+                            r[(gq + 1) & 1][jj] = *(const volatile lds_f32x4*)(size_t)row_addr(j0 + 5 + jj);
                 }
 #pragma unroll
                 for (int jj = 0; jj < 5; ++jj) {
                     const int j = j0 + jj;
                     if (j < K) {
-                        a12[j] = __builtin_elementwise_fma(dy2, f32x2{r[jj][0], r[jj][1]}, a12[j]);
-                        a3[j] = fmaf(dyv, r[jj][2], a3[j]);
+                        a12[j] = __builtin_elementwise_fma(dy2, f32x2{r[gq & 1][jj][0], r[gq & 1][jj][1]}, a12[j]);
+                        a3[j] = fmaf(dyv, r[gq & 1][jj][2], a3[j]);
                         // pinned here: otherwise the sums sink below the N loop into the loop latch
                         // and all K rows (4K registers) stay live across it
                         KEEP(a12[j]); KEEP(a3[j]);

@@ -40,7 +40,9 @@ struct explainn_ctx {
     uint32_t* pk2;        // [PW][Bs]         2-bit codes, 16 positions per word (N -> 0)
     uint32_t* nmask;      // [NW][Bs]         1 bit per position, set where N
     int PW, NW;
-    int* cnt;             // [k][L][16]       pair counts (gap d, position q, a*4+a')
+    unsigned long long* bm;  // [4][tiles][Lp] the batch as bit masks per (base, position): bit b of tile t
+                          //                = sequence 64t+b has that base there (train mode, pack.hip)
+    int Lp;               // positions per bm row (the pack grid's coverage: NW*32 rounded up to 64)
     double* G;            // [4k][4k]         mean window-indicator second moment
     double* m;            // [4k]             mean window indicator
     float* alpha;         // [U4]             BN1 scale   gamma1/sigma1

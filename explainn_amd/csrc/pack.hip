@@ -4,8 +4,9 @@
 //
 //   pack_onehot   x (B,4,L) fp32  ->  codesT [L][Bs] u8   (0..3, 4 = N / padding lanes),
 //                 pk2 [PW][Bs] (2 bit/base) and nmask [NW][Bs] (1 bit/base) from the same tile
-//   pair_counts   cnt[d][q][a*4+a'] = #{b : s[b,q]=a and s[b,q+d]=a'}           (exact, int)
-//   gram          G[(a,j),(a',j')] = (1/N) sum_{q=j}^{j+Lo-1} cnt[j'-j][q][a,a'],  m = diag(G)
+//                 and (train mode) bm [4][tiles][Lp] u64: the batch as bit masks per (base, position)
+//   moments       cnt[d][q][a,a'] = #{b : s[b,q]=a and s[b,q+d]=a'} = popc(bm[a][q] & bm[a'][q+d])
+//                 (exact, int);  G[(a,j),(a',j')] = (1/N) sum_{q=j}^{j+Lo-1} cnt[j'-j][q][a,a'],  m = diag(G)
 //
 // This is the only stage that touches the HBM-resident input: 16*L bytes per sequence.
 #include "common.h"
@@ -14,12 +15,15 @@
 // (B,L) byte matrix of base codes 0..3 = A,C,G,T, 4 = N -- 16x less input traffic, no fp32 one-hot
 // in HBM at all -- optionally reverse-complemented on the fly (code' [p] = 3 - code[L-1-p], N stays
 // N: sequence/__init__.py:59-61 flips both axes of the one-hot).
+__device__ __forceinline__ int gridDim_x_tiles(int B) { return (B + 63) / 64; }
+
 template <bool CODES>
 __device__ __forceinline__ void pack_tile(const float* __restrict__ x,
                                           const uint8_t* __restrict__ codes_in, int rc,
                                           uint8_t* __restrict__ codesT, uint32_t* __restrict__ pk2,
                                           uint32_t* __restrict__ nmask, int B, int L, int Bs, int PW,
-                                          int NW, int* __restrict__ flags, int bx, int by) {
+                                          int NW, int* __restrict__ flags, int bx, int by,
+                                          unsigned long long* __restrict__ bm, int Lp) {
     __shared__ uint8_t tile[64][68];
     const int b0 = bx * 64, p0 = by * 64;
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -100,6 +104,25 @@ __device__ __forceinline__ void pack_tile(const float* __restrict__ x,
             if (ni < NW) nmask[(size_t)ni * Bs + b0 + lane] = nm;
         }
     }
+    // train mode: the batch as bit masks per (base, position) -- bit b of bm[a][tile][p] says
+    // "sequence 64*tile + b has base a at position p" -- one ballot per (position, base) of the
+    // tile; the moment kernel counts base pairs with AND + popcount on them.  N and the padding
+    // lanes set no bit.  Wave q takes positions [16q, 16q+16): lane 16a + i keeps ballot (a, i).
+    if (bm != nullptr) {
+        const bool live = b0 + lane < B;
+        unsigned long long mine = 0ull;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t c = tile[lane][16 * q + i];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const unsigned long long bal = __ballot(live && c == (uint32_t)a);
+                mine = (lane == 16 * a + i) ? bal : mine;
+            }
+        }
+        const int a = lane >> 4, pq = p0 + 16 * q + (lane & 15);
+        if (pq < Lp) bm[((size_t)a * gridDim_x_tiles(B) + bx) * Lp + pq] = mine;
+    }
     if (bad) atomicOr(flags, 1);
 }
 
@@ -111,8 +134,10 @@ __global__ __launch_bounds__(256) void pack_onehot_kernel(const float* __restric
                                                           uint32_t* __restrict__ pk2,
                                                           uint32_t* __restrict__ nmask, int B,
                                                           int L, int Bs, int PW, int NW,
-                                                          int* __restrict__ flags) {
-    pack_tile<CODES>(x, codes_in, rc, codesT, pk2, nmask, B, L, Bs, PW, NW, flags, blockIdx.x, blockIdx.y);
+                                                          int* __restrict__ flags,
+                                                          unsigned long long* __restrict__ bm, int Lp) {
+    pack_tile<CODES>(x, codes_in, rc, codesT, pk2, nmask, B, L, Bs, PW, NW, flags, blockIdx.x, blockIdx.y,
+                     bm, Lp);
 }
 
 // Train forward: the pack tiles and the per-unit filter tables (which depend only on the weights)
@@ -126,75 +151,63 @@ __global__ __launch_bounds__(256) void pack_tables_kernel(const float* __restric
                                                           int* __restrict__ flags, int gx, int gy,
                                                           const float* __restrict__ conv_w,
                                                           float* __restrict__ Wt,
-                                                          float* __restrict__ lut, int U, int k) {
+                                                          float* __restrict__ lut, int U, int k,
+                                                          unsigned long long* __restrict__ bm, int Lp) {
     __shared__ float wsh[4 * MAX_K];
     const int blk = blockIdx.x;                        // block-uniform role
     if (blk < gx * gy)
-        pack_tile<false>(x, nullptr, 0, codesT, pk2, nmask, B, L, Bs, PW, NW, flags, blk % gx, blk / gx);
+        pack_tile<false>(x, nullptr, 0, codesT, pk2, nmask, B, L, Bs, PW, NW, flags, blk % gx, blk / gx,
+                         bm, Lp);
     else
         filter_tables_unit(conv_w, Wt, lut, U, k, blk - gx * gy, threadIdx.x, 256, wsh);
 }
 
-// one wavefront per (gap d, position q); lanes stride over the batch, the 16 pair bins are
-// counted with ballots so the counters live in scalar registers
-__global__ __launch_bounds__(256) void pair_counts_kernel(const uint8_t* __restrict__ codesT,
-                                                          int* __restrict__ cnt, int B, int L,
-                                                          int k, int Bs) {
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (wid >= k * L) return;
-    const int d = wid / L, q = wid % L;
-    int c[16];
+// Input moments in ONE launch (round 1: 3800 thin ballot waves for the pair counts + a Gram kernel,
+// 24 + 9 us on the side stream, stretching the filter bank that runs beside them).
+// One block per (gap d, base pair (a, a')): thread <-> position q,
+//   cnt[q] = #{b : s[b,q] = a and s[b,q+d] = a'} = sum over 64-sequence tiles of popc(bm[a][q] & bm[a'][q+d])
+// (exact integers), then every entry of G on this block's diagonal is a sum of Lo consecutive cnt:
+//   G[(a,j),(a',j+d)] = (1/N) sum_{q=j}^{j+Lo-1} cnt[q]  = (T0 - sum_{q<j} cnt[q] + sum_{q=Lo}^{Lo+j-1} cnt[q]) / N,
+// T0 = the first window's sum (block reduction), and m = diag(G).
+__global__ __launch_bounds__(256) void moments_kernel(const unsigned long long* __restrict__ bm,
+                                                      double* __restrict__ G, double* __restrict__ m,
+                                                      int B, int L, int k, int Lp) {
+    extern __shared__ int cq[];                        // [L] pair counts of this (d, a, a'), then 4 partial sums
+    const int d = blockIdx.x >> 4, a = (blockIdx.x >> 2) & 3, a2 = blockIdx.x & 3;
+    const int tid = threadIdx.x, NT = (B + 63) / 64, Lo = L - k + 1, K4 = 4 * k;
+    const unsigned long long* __restrict__ m0 = bm + (size_t)a * NT * Lp;
+    const unsigned long long* __restrict__ m1 = bm + (size_t)a2 * NT * Lp + d;
+    long long part = 0;
+    for (int q = tid; q < L; q += 256) {
+        int c = 0;
+        if (q + d < L) {
+            for (int t0 = 0; t0 < NT; t0 += 8) {           // sixteen 8-byte loads in flight
+                unsigned long long x0[8], x1[8];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) c[i] = 0;
-    if (q + d < L) {
-        const uint8_t* r0 = codesT + (size_t)q * Bs;
-        const uint8_t* r1 = codesT + (size_t)(q + d) * Bs;
-        for (int bb = lane; bb < ((B + 63) & ~63); bb += 256) {
-            int s0v[4], s1v[4];
+                for (int i = 0; i < 8; ++i) {
+                    const size_t o = (size_t)min(t0 + i, NT - 1) * Lp + q;
+                    x0[i] = m0[o]; x1[i] = m1[o];
+                }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {                  // eight byte loads in flight
-                const int bc = min(bb + 64 * r, B - 1);
-                s0v[r] = r0[bc];
-                s1v[r] = r1[bc];
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { KEEP(s0v[r]); KEEP(s1v[r]); }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int id = -1;
-                if (bb + 64 * r < B && s0v[r] < 4 && s1v[r] < 4) id = s0v[r] * 4 + s1v[r];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) c[i] += __popcll(__ballot(id == i));
+                for (int i = 0; i < 8; ++i) c += (t0 + i < NT) ? __popcll(x0[i] & x1[i]) : 0;
             }
         }
+        cq[q] = c;
+        if (q < Lo) part += c;
     }
-    int mine = 0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) mine = (lane == i) ? c[i] : mine;
-    if (lane < 16) cnt[(size_t)wid * 16 + lane] = mine;
-}
-
-// one wavefront per entry of G (lanes stride over the Lo positions, shuffle reduce);
-// row/col index (a,j) -> a*k + j (the flattening of a (4,k) filter)
-__global__ __launch_bounds__(256) void gram_kernel(const int* __restrict__ cnt,
-                                                   double* __restrict__ G, double* __restrict__ m,
-                                                   int B, int L, int k) {
-    const int K4 = 4 * k;
-    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (e >= K4 * K4) return;
-    const int row = e / K4, col = e % K4;
-    int a = row / k, j = row % k, a2 = col / k, j2 = col % k;
-    if (j > j2) { int t = a; a = a2; a2 = t; t = j; j = j2; j2 = t; }
-    const int d = j2 - j, Lo = L - k + 1;
-    const int* src = cnt + ((size_t)d * L + j) * 16 + a * 4 + a2;
-    long long s = 0;
-    for (int q = lane; q < Lo; q += 64) s += src[(size_t)q * 16];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (lane == 0) {
-        const double v = (double)s / ((double)B * (double)Lo);
-        G[e] = v;
+    long long* red = reinterpret_cast<long long*>(cq + ((L + 1) & ~1));
+    part = (long long)wave_sum_d((double)part);        // exact: the sums stay far below 2^53
+    if ((tid & 63) == 0) red[tid >> 6] = part;
+    __syncthreads();
+    const long long T0 = red[0] + red[1] + red[2] + red[3];
+    if (tid < k - d) {
+        const int j = tid;
+        long long sj = T0;
+        for (int q = 0; q < j; ++q) sj += cq[Lo + q] - cq[q];
+        const double v = (double)sj / ((double)B * (double)Lo);
+        const int row = a * k + j, col = a2 * k + j + d;
+        G[(size_t)row * K4 + col] = v;
+        G[(size_t)col * K4 + row] = v;
         if (row == col) m[row] = v;
     }
 }
@@ -215,7 +228,7 @@ int launch_pack(explainn_ctx* c, const float* x, int B, bool counts, hipStream_t
         // position tiles cover the padded tail too, so the packed words past L are written (as zeros)
         hipLaunchKernelGGL(pack_onehot_kernel<false>, dim3(gb, (c->NW * 32 + 63) / 64), dim3(256), 0,
                            s, x, (const uint8_t*)nullptr, 0, c->codesT, c->pk2, c->nmask, B, c->L,
-                           c->Bs, c->PW, c->NW, c->flags);
+                           c->Bs, c->PW, c->NW, c->flags, counts ? c->bm : nullptr, c->Lp);
         LAUNCH_CHECK();
     }
     if (counts) return launch_moments(c, B, s);
@@ -228,7 +241,7 @@ int launch_pack_tables(explainn_ctx* c, const float* x, const explainn_params* p
     c->staged_B = 0;
     hipLaunchKernelGGL(pack_tables_kernel, dim3(gx * gy + c->U4), dim3(256), 0, s, x, c->codesT,
                        c->pk2, c->nmask, B, c->L, c->Bs, c->PW, c->NW, c->flags, gx, gy, p->conv_w,
-                       c->Wt, c->lut, c->U, c->k);
+                       c->Wt, c->lut, c->U, c->k, c->bm, c->Lp);
     LAUNCH_CHECK();
     return EXPLAINN_OK;
 }
@@ -236,22 +249,18 @@ int launch_pack_tables(explainn_ctx* c, const float* x, const explainn_params* p
 int launch_pack_codes(explainn_ctx* c, const uint8_t* codes, int B, int rc, hipStream_t s) {
     hipLaunchKernelGGL(pack_onehot_kernel<true>, dim3((B + 63) / 64, (c->NW * 32 + 63) / 64),
                        dim3(256), 0, s, (const float*)nullptr, codes, rc, c->codesT, c->pk2, c->nmask,
-                       B, c->L, c->Bs, c->PW, c->NW, c->flags);
+                       B, c->L, c->Bs, c->PW, c->NW, c->flags, c->bm, c->Lp);
     LAUNCH_CHECK();
     c->staged_B = B;
     return EXPLAINN_OK;
 }
 
-// input moments (train mode): pair counts -> Gram matrix of the window indicator
+// input moments (train mode): bit masks (written by the pack kernel) -> Gram matrix of the window
+// indicator, one launch
 int launch_moments(explainn_ctx* c, int B, hipStream_t s) {
-    {
-        const int waves = c->k * c->L;
-        hipLaunchKernelGGL(pair_counts_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, c->codesT,
-                           c->cnt, B, c->L, c->k, c->Bs);
-        LAUNCH_CHECK();
-        hipLaunchKernelGGL(gram_kernel, dim3((c->K4 * c->K4 + 3) / 4), dim3(256), 0, s, c->cnt,
-                           c->G, c->m, B, c->L, c->k);
-        LAUNCH_CHECK();
-    }
+    const size_t sm = (size_t)((c->L + 1) & ~1) * sizeof(int) + 4 * sizeof(long long);
+    hipLaunchKernelGGL(moments_kernel, dim3(c->k * 16), dim3(256), sm, s, c->bm, c->G, c->m, B, c->L,
+                       c->k, c->Lp);
+    LAUNCH_CHECK();
     return EXPLAINN_OK;
 }

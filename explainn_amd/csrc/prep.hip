@@ -54,15 +54,32 @@ __global__ __launch_bounds__(128) void prep1_stats_kernel(
         return;
     }
     for (int i = tid; i < K4; i += 128) wsh[i] = (double)conv_w[(size_t)u * K4 + i];
+    // G (K4 x K4 doubles, 46 KB at k = 19) is staged in LDS with every load of a thread in flight at
+    // once: the product below then never waits on global memory (walking G from global was ten
+    // dependent round trips per block, 9-13 us for a kernel with 1.7 MFLOP of work)
+    extern __shared__ double Gs[];
+    {
+        const int n2 = K4 * K4;
+        for (int e0 = tid; e0 < n2; e0 += 128 * 16) {
+            double gv[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) gv[q] = G[min(e0 + q * 128, n2 - 1)];
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (e0 + q * 128 < n2) Gs[e0 + q * 128] = gv[q];
+        }
+    }
     __syncthreads();
     double mu_p = 0, q_p = 0;
     for (int i = tid; i < K4; i += 128) {
-        // two independent chains over the row of G
+        // (G w)[i] = sum_c G[c][i] w[c] (G is symmetric): column i, consecutive lanes = consecutive doubles
         double g0 = 0, g1s = 0;
-        const double* Gr = G + (size_t)i * K4;
-        int i2 = 0;
-        for (; i2 + 1 < K4; i2 += 2) { g0 = fma(Gr[i2], wsh[i2], g0); g1s = fma(Gr[i2 + 1], wsh[i2 + 1], g1s); }
-        for (; i2 < K4; ++i2) g0 = fma(Gr[i2], wsh[i2], g0);
+        int c0 = 0;
+        for (; c0 + 1 < K4; c0 += 2) {
+            g0 = fma(Gs[c0 * K4 + i], wsh[c0], g0);
+            g1s = fma(Gs[(c0 + 1) * K4 + i], wsh[c0 + 1], g1s);
+        }
+        if (c0 < K4) g0 = fma(Gs[c0 * K4 + i], wsh[c0], g0);
         const double gw = g0 + g1s;
         Gw[(size_t)u * K4 + i] = gw;
         mu_p = fma(wsh[i], m[i], mu_p);
@@ -95,7 +112,8 @@ int launch_prep1_tables(explainn_ctx* c, const explainn_params* p, hipStream_t s
 
 int launch_prep1(explainn_ctx* c, const explainn_params* p, int B, bool train, hipStream_t s) {
     if (train)
-        hipLaunchKernelGGL(prep1_stats_kernel<true>, dim3(c->U4), dim3(128), 0, s, p->conv_w,
+        hipLaunchKernelGGL(prep1_stats_kernel<true>, dim3(c->U4), dim3(128),
+                           (size_t)c->K4 * c->K4 * sizeof(double), s, p->conv_w,
                            p->conv_b, p->bn1_w, p->bn1_b, p->bn1_rm, p->bn1_rv, p->bn1_nbt, c->G,
                            c->m, c->alpha, c->shift, c->mug, c->sig1, c->Gw, c->U, c->k, B, c->Lo);
     else
@@ -586,6 +604,10 @@ int prep_configure(explainn_ctx* c) {
                                     (int)qmom_big_lds<N>()))
     NQ_DISPATCH(c->NQ, CALL);
 #undef CALL
+    if ((size_t)c->K4 * c->K4 * sizeof(double) > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&prep1_stats_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)((size_t)c->K4 * c->K4 * sizeof(double))));
     const size_t sm = prep2_lds(c->n, c->NS);
     if (sm > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&prep2_kernel<true>),

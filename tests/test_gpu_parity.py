@@ -622,3 +622,46 @@ def test_graph_replay_equals_direct_launches():
     # BatchNorm buffers advanced identically (they are updated inside the captured kernels)
     for (ka, va), (kb, vb) in zip(direct.model.state_dict().items(), graphed.model.state_dict().items()):
         assert torch.equal(va, vb), ka
+
+
+def test_eval_tables_follow_parameter_changes():
+    """The eval entry points keep their folded tables (filter LUTs, BatchNorm folds, FC1 fragments)
+    between calls and rebuild them when explainn_params.version moves.  Every way the values can
+    change must move it: an in-place torch update, a train-mode step of this package (BatchNorm
+    buffers written through raw pointers), the fused Adam launch, load_state_dict, and a
+    re-assigned Parameter."""
+    from explainn_amd import get_optimizer
+    U, k, L, T, B = 4, 9, 60, 2, 24
+    sd = orc.random_state_dict(U, k, L, T, seed=71)
+    m = _model(sd, U, k, L, T)
+    x = orc.random_onehot(B, L, seed=72, n_frac=0.02)
+    xt = torch.from_numpy(x).cuda()
+
+    def check(what):
+        cur = {key: _np(v) for key, v in m.state_dict().items()}
+        m.eval()
+        with torch.no_grad():
+            a = m(xt)
+            b = m(xt)                                 # second call: cached tables
+        assert torch.equal(a, b)
+        _close(_np(a), orc.forward(cur, x), what=what)
+
+    check("initial")
+    with torch.no_grad():
+        m.linears[0].weight.mul_(1.5)                 # in-place torch op
+        m.linears[7].running_var.add_(0.3)
+    check("after in-place updates")
+    m.train()
+    m.dropout_p = 0.0
+    out = m(xt)                                       # train forward: buffers move, tables overwritten
+    out.sum().backward()
+    check("after a train-mode forward/backward")
+    opt = get_optimizer(m.parameters(), 0.01)
+    m.train()
+    torch.nn.functional.binary_cross_entropy_with_logits(m(xt), torch.ones(B, T).cuda()).backward()
+    opt.step()                                        # fused Adam: raw-pointer update
+    check("after a fused Adam step")
+    m.load_state_dict({key: torch.from_numpy(np.array(v)) for key, v in sd.items()})
+    check("after load_state_dict")
+    m.final.weight = torch.nn.Parameter(m.final.weight.detach() * 2)
+    check("after re-assigning a Parameter")

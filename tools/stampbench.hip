@@ -57,7 +57,7 @@ int main() {
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
         if (rep) report("qmom", QCH * U, 4, ms);
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((fc_fwd_kernel<26, 2>), dim3(4, U), dim3(256), fc_fwd_lds<26>(), 0, ext, alpha, shift, A2f, sh2, V2, bits, z, (const uint8_t*)nullptr, 19661u, 1.4285715f, 1u, 2u, fz, fz, fz, fz, fz, o, n, Bs, B, U, (const uint32_t*)nullptr);
+        hipLaunchKernelGGL((fc_fwd_kernel<26, 2>), dim3(4, U), dim3(256), fc_fwd_lds<26>(), 0, ext, alpha, shift, A2f, sh2, V2, bits, z, (const uint8_t*)nullptr, 19661u, 1.4285715f, 1u, 2u, fz, fz, fz, fz, fz, o, n, Bs, B, U, (const uint32_t*)nullptr, 0, 4);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
         if (rep) report("fc_fwd", 4 * U * 4, 5, ms);
         CK(hipEventRecord(e0));
@@ -65,7 +65,7 @@ int main() {
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
         if (rep) report("passA", ACH * U, 4, ms);
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(passB_kernel<26>, dim3(4, U, 1), dim3(256), passB_lds<26>(), 0, ext, alpha, shift, dz, bits, Tt, M, k0p, mug, sig1, dy, S12p, n, Bs, B); // (tables passed as fragment-ordered stand-ins)
+        hipLaunchKernelGGL(passB_kernel<26>, dim3(4, U, 1), dim3(256), passB_lds<26>(), 0, ext, alpha, shift, dz, bits, Tt, M, k0p, mug, sig1, dy, S12p, n, Bs, B, U, 0, 4); // (tables passed as fragment-ordered stand-ins)
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
         if (rep) report("passB", 4 * U * 4, 6, ms);
     }
