@@ -1,18 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- sequences/sec (fwd+bwd) of the ExplaiNN hot path on MI355X.
 
-Workload (BASELINE.json configs[1], the configuration the metric is quoted on):
-  300-unit ExplaiNN, kernel 19, 200 bp one-hot, 1 binary task, batch 1024 PER GPU, fp32.
+Default workload (BASELINE.json configs[1], the configuration the metric is quoted on):
+  C2: 300-unit ExplaiNN, kernel 19, 200 bp one-hot, 1 binary task, batch 1024 PER GPU, fp32.
 A step = one pass of the hot path over one synthetic batch already resident in HBM:
 train-mode forward (dropout 0.3 active) + BCE-with-logits loss + backward into a flat gradient
-buffer, plus -- for N > 1 -- one RCCL all-reduce of that buffer (weak scaling, batch sharding).
+buffer, plus -- for N > 1 -- one RCCL all-reduce of that buffer.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C2|C3|C4|C5] [--scaling weak|strong]
   (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`)
+
+--scaling weak (default): every GPU takes the workload's per-GPU batch.  --scaling strong: the
+workload's GLOBAL batch (C4: 8192 x 1000 bp x 50 tasks) is split over the N ranks.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md section 6 for every field).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -24,25 +28,59 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
-U, K, L, T, B_PER_GPU = 300, 19, 200, 1, 1024
+K = 19
+# BASELINE.json configs[1..4]: units, length, tasks, per-GPU batch of the
+# weak-scaling run, global batch of the strong-scaling run
+WORKLOADS = {
+    "C2": dict(U=300, L=200, T=1, B=1024, G=8192,
+               text="C2: 300-unit ExplaiNN, k=19, 200 bp one-hot, 1 binary task, batch 1024 per GPU"),
+    "C3": dict(U=300, L=200, T=50, B=4096, G=4096,
+               text="C3: 300-unit, 200 bp, 50 binary tasks, batch 4096 per GPU"),
+    "C4": dict(U=300, L=1000, T=50, B=1024, G=8192,
+               text="C4: 300-unit, 1000 bp, 50 binary tasks, global batch 8192 (1024 per GPU at 8 GPUs)"),
+    "C5": dict(U=2000, L=600, T=164, B=1024, G=8192,
+               text="C5: 2000-unit, 600 bp, 164 binary tasks, global batch 8192 (1024 per GPU at 8 GPUs), fp32"),
+}
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TFLOPS = 157.3      # same guide: fp32 MFMA = fp32 vector rate
+LDS_PEAK_GBPS = 150000.0          # ds_read_b64/b128 aggregate
+CLOCK_HZ, SIMDS = 2.4e9, 1024
 
 
-def algorithmic_bytes_per_step(B, P):
+def algorithmic_bytes_per_step(B, L, T, P):
     """SURVEY.md 8(d): per sequence 16*L (fp32 one-hot in) + 8*T (targets in, logits out);
     per step 2*4*P (parameters read, gradients written)."""
     return B * (16 * L + 8 * T) + 2 * 4 * P
 
 
-def measured_traffic():
-    """HBM bytes per step from the PMC passes committed under profiles/ (rocprofv3 cannot run inside
-    this process); None if the file is absent or was taken on another workload."""
-    path = os.path.join(ROOT, "profiles", "r01_final_traffic.json")
+def csrc_sha():
+    """Hash of the kernel sources: ties the committed PMC summaries to the code they were taken on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "explainn_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as fh:
+                h.update(name.encode()); h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def committed_counters(workload):
+    """Per-kernel PMC counters of the training step (profiles/*_counters.json, written by
+    tools/final_profile.sh from separate rocprofv3 --pmc passes; rocprofv3 cannot run inside this
+    process).  Used only when they were taken on exactly these kernel sources and this workload:
+    otherwise every figure derived from them is reported as null."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
     try:
-        with open(path) as fh:
-            return int(json.load(fh)["traffic_bytes_per_step"])
+        for name in sorted(os.listdir(pdir)):
+            if name.endswith("_counters.json"):
+                with open(os.path.join(pdir, name)) as fh:
+                    d = json.load(fh)
+                if d.get("csrc_sha") == csrc_sha() and d.get("workload") == workload:
+                    best = dict(d, file="profiles/" + name)
     except Exception:
         return None
+    return best
 
 
 def measured_copy_peak(device):
@@ -65,7 +103,7 @@ def measured_copy_peak(device):
     return round(gbps, 1)
 
 
-def synthetic_batch(B, seed, device, n_frac=0.0):
+def synthetic_batch(B, L, T, seed, device, n_frac=0.0):
     g = torch.Generator().manual_seed(seed)
     idx = torch.randint(0, 4, (B, L), generator=g)
     x = torch.zeros(B, 4, L).scatter_(1, idx[:, None, :], 1.0)
@@ -75,10 +113,12 @@ def synthetic_batch(B, seed, device, n_frac=0.0):
     return x.to(device), y.to(device)
 
 
-def cpu_baseline(budget_s=20.0):
+def cpu_baseline(w, budget_s=24.0):
     """The stock-PyTorch CPU restatement of the reference (oracle/torch_ref.py, pinned to the
     reference's outputs by tests/test_torch_ref_golden.py), timed on this box's host cores on a
-    bounded sample of the same workload: whole C2 batches of 1024 until ~budget_s is used."""
+    bounded sample of the same workload: whole batches until about half the budget is used with
+    this job's core share, then the same with ONE thread -- the reference's own default
+    (`--cpu-threads 1`, train.py:43-48)."""
     from oracle import torch_ref
     cores = os.cpu_count() or 1
     try:
@@ -88,22 +128,51 @@ def cpu_baseline(budget_s=20.0):
     # a 1-GPU box gives this job a 16-core share of the host (more threads only oversubscribe:
     # 256 threads measured 72 seq/s against 16 threads' several hundred)
     cores = min(cores, int(os.environ.get("EXPLAINN_CPU_THREADS", "16")))
+    sd = torch_ref.init_state(w["U"], K, w["L"], w["T"], seed=0)
+    x, y = synthetic_batch(w["B"], w["L"], w["T"], 1, "cpu")
+
+    def timed(threads, budget, max_steps):
+        torch.set_num_threads(threads)
+        torch_ref.train_step(sd, x, y)                  # warm-up (allocations, oneDNN primitives)
+        t0 = time.perf_counter()
+        steps = 0
+        while True:
+            torch_ref.train_step(sd, x, y)
+            steps += 1
+            el = time.perf_counter() - t0
+            if el >= budget or steps >= max_steps:
+                break
+        return steps, el
+
+    steps, el = timed(cores, budget_s / 2, 20)
+    out = {"value": round(steps * w["B"] / el, 1), "unit": "sequences/s", "cores": cores, "kind": "port",
+           "sample": "%d train steps (fwd+BCE+bwd, dropout 0.3) of the %s workload, stock-PyTorch CPU "
+                     "ops, %d threads, %.1f s" % (steps, w["text"].split(":")[0], cores, el)}
+    s1, e1 = timed(1, budget_s / 2, 2)
+    out["one_thread"] = {"value": round(s1 * w["B"] / e1, 1), "unit": "sequences/s", "cores": 1,
+                         "sample": "%d train step(s), 1 thread (the reference's default -c 1), %.1f s" % (s1, e1)}
     torch.set_num_threads(cores)
-    sd = torch_ref.init_state(U, K, L, T, seed=0)
-    x, y = synthetic_batch(B_PER_GPU, 1, "cpu")
-    torch_ref.train_step(sd, x, y)                      # warm-up (allocations, oneDNN primitives)
-    t0 = time.perf_counter()
-    steps = 0
-    while True:
-        torch_ref.train_step(sd, x, y)
-        steps += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or steps >= 20:
-            break
-    return {"value": round(steps * B_PER_GPU / el, 1), "unit": "sequences/s", "cores": cores,
-            "kind": "port",
-            "sample": "%d train steps (fwd+BCE+bwd, dropout 0.3) of the 300-unit/200bp/batch-1024 "
-                      "workload, stock-PyTorch CPU ops, %d threads, %.1f s" % (steps, cores, el)}
+    return out
+
+
+def kernel_model(w, B):
+    """Work of the heavy kernels of one training step, from the shapes alone:
+    the resource that binds each and the amount of it, so that a live duration turns into a
+    fraction of that resource's peak."""
+    U, L, T = w["U"], w["L"], w["T"]
+    Lo = L - K + 1
+    n = Lo // 7
+    nt = (K + 1) // 2
+    return {
+        # exact-fp32 MFMA FLOPs on the UNPADDED problem (100 hidden channels, n pooled positions)
+        "fc_fwd": ("mfma_f32", 2.0 * 100 * n * B * U),
+        "passA": ("mfma_f32", 2.0 * 100 * n * B * U),
+        "passB": ("mfma_f32", 2.0 * (100 + n) * n * B * U),
+        # LDS bytes the gather reads: one 8-byte dinucleotide row per (sequence, unit pair, position, tap pair)
+        "conv_pool": ("lds", 8.0 * nt * Lo * B * U / 2),
+        # one 16-byte one-hot row per (sequence, unit, pooled position, tap)
+        "conv_bwd": ("lds", 16.0 * K * n * B * U),
+    }
 
 
 def main():
@@ -111,14 +180,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="C2")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-seconds", type=float, default=24.0)
     ap.add_argument("--n-frac", type=float, default=0.0,
                     help="fraction of N bases in the synthetic batch (robustness variant; the "
                          "headline is 0)")
     ap.add_argument("--skip-optimizer", action="store_true",
                     help="skip the secondary fwd+bwd+Adam timing (profiling runs: one leg only)")
+    ap.add_argument("--skip-stage-times", action="store_true",
+                    help="skip the per-kernel HIP-event leg (profiling runs)")
     args = ap.parse_args()
+    w = WORKLOADS[args.workload]
+    U, L, T = w["U"], w["L"], w["T"]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -129,6 +204,12 @@ def main():
                              "--nproc-per-node %d" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if args.scaling == "strong":
+        if w["G"] % world:
+            raise SystemExit("global batch %d does not split over %d ranks" % (w["G"], world))
+        B = w["G"] // world
+    else:
+        B = w["B"]
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -150,7 +231,7 @@ def main():
     model.validate_input = False          # flags are checked once, after the timed region
     if world > 1:
         broadcast_parameters(model)
-    eng = StepEngine(model, B_PER_GPU, loss="binary")
+    eng = StepEngine(model, B, loss="binary")
     sync = (GradAllReduce(eng.flat_grad, split=eng.conv_grad_elements, force=force_sync)
             if dist is not None else None)
     # Default: ONE all-reduce of the flat buffer after the step.  EXPLAINN_BENCH_OVERLAP=1 switches to
@@ -158,7 +239,7 @@ def main():
     # one-rank rehearsal its second collective cost more than the overlap saved
     overlap = os.environ.get("EXPLAINN_BENCH_OVERLAP", "0") == "1"
     P = eng.flat_grad.numel()
-    x, y = synthetic_batch(B_PER_GPU, 1000 + rank, dev, args.n_frac)
+    x, y = synthetic_batch(B, L, T, 1000 + rank, dev, args.n_frac)
 
     def one_step(i):
         if overlap:
@@ -202,6 +283,21 @@ def main():
             opt.step()
         fence()
         wall_opt = time.perf_counter() - t1
+    # per-kernel durations, live: HIP events recorded by the library on the launch stream around
+    # every stage of the step (explainn_stage_timing), averaged over a few steps after the timed
+    # region (the events themselves cost time, so this leg is separate)
+    stage_us = None
+    if not args.skip_stage_times and rank == 0 and world == 1:
+        eng.ctx.stage_timing(True)
+        acc, reps = {}, 10
+        for i in range(reps + 2):
+            one_step(10 ** 6 + i)
+            t = eng.ctx.stage_times()
+            if i >= 2:
+                for k_, v in t.items():
+                    acc[k_] = acc.get(k_, 0.0) + v
+        eng.ctx.stage_timing(False)
+        stage_us = {k_: round(v / reps, 2) for k_, v in acc.items()}
     flags = model.input_flags()
     assert flags == 0, "synthetic input flagged as not one-hot"
     assert torch.isfinite(eng.loss).all() and torch.isfinite(eng.flat_grad).all()
@@ -211,23 +307,52 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall, wall_opt = float(t[0].item()), float(t[1].item())
     if rank == 0:
-        seqs = B_PER_GPU * world * args.steps
+        seqs = B * world * args.steps
         step_gpu_s = gpu_ms / 1e3 / args.steps
-        alg = algorithmic_bytes_per_step(B_PER_GPU, P)
+        alg = algorithmic_bytes_per_step(B, L, T, P)
         achieved = alg / step_gpu_s / 1e9
-        traffic = measured_traffic() if world == 1 else None
+        counters = committed_counters(args.workload) if (world == 1 and B == w["B"]) else None
+        traffic = counters["traffic_bytes_per_step"] if counters else None
         copy_peak = measured_copy_peak(dev) if world == 1 else None
+        if args.workload == "C2":
+            metric = "sequences/sec (fwd+bwd), 200bp one-hot, 300 units, batch 1024"
+        else:
+            metric = "sequences/sec (fwd+bwd), %d bp one-hot, %d units, %d tasks" % (L, U, T)
+        kernels = None
+        dominant = None
+        if stage_us:
+            model_k = kernel_model(w, B)
+            kernels = {}
+            for name, us in sorted(stage_us.items(), key=lambda kv: -kv[1]):
+                ent = {"us": us}
+                if name in model_k:
+                    kind, work = model_k[name]
+                    if kind == "mfma_f32":
+                        ent.update(bound="mfma_f32", unpadded_gflop=round(work / 1e9, 3),
+                                   mfma_frac=round(work / (us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4))
+                    else:
+                        ent.update(bound="lds+valu", lds_gbytes=round(work / 1e9, 3),
+                                   lds_frac=round(work / (us * 1e-6) / 1e9 / LDS_PEAK_GBPS, 4))
+                pc = (counters or {}).get("per_kernel", {}).get(name)
+                if pc:
+                    # VALU issue: SQ_INSTS_VALU wave-instructions x 4 cycles on 1024 SIMDs at 2.4 GHz
+                    if pc.get("SQ_INSTS_VALU"):
+                        ent["valu_frac"] = round(pc["SQ_INSTS_VALU"] * 4 / SIMDS / CLOCK_HZ / (us * 1e-6), 4)
+                    if pc.get("hbm_bytes"):
+                        ent["hbm_MB"] = round(pc["hbm_bytes"] / 1e6, 1)
+                        ent["hbm_frac"] = round(pc["hbm_bytes"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
+                kernels[name] = ent
+            dominant = max(stage_us, key=stage_us.get)
         out = {
-            "metric": "sequences/sec (fwd+bwd), 200bp one-hot, 300 units, batch 1024",
+            "metric": metric,
             "value": round(seqs / wall, 1), "unit": "sequences/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2: 300-unit ExplaiNN, k=19, 200 bp one-hot, 1 binary task, "
-                                   "batch 1024 per GPU, train fwd + BCE + bwd (dropout 0.3)"
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": w["text"] + ", train fwd + BCE + bwd (dropout 0.3)"
                                    + (", RCCL all-reduce of the flat gradient" if dist is not None else ""),
                        "cnn_units": U, "kernel_size": K, "sequence_length": L, "n_features": T,
-                       "batch_per_gpu": B_PER_GPU, "global_batch": B_PER_GPU * world,
+                       "batch_per_gpu": B, "global_batch": B * world,
                        "parameters": P, "parallelism": "dp%d" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
@@ -236,19 +361,28 @@ def main():
                          # measured bytes / this run's GPU time; includes Infinity-Cache hits
                          "measured_GBps": round(traffic / step_gpu_s / 1e9, 1) if traffic else None,
                          "measured_frac": round(traffic / step_gpu_s / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None,
-                         "traffic_note": "bytes per step, FETCH_SIZE(x2)+WRITE_SIZE from profiles/"
-                                         "r01_final_traffic.json (separate rocprofv3 --pmc passes)",
+                         "traffic_note": ("bytes per step, FETCH_SIZE(x2)+WRITE_SIZE from %s (separate "
+                                          "rocprofv3 --pmc passes on these kernel sources, csrc_sha %s)"
+                                          % (counters["file"], counters["csrc_sha"])) if counters else
+                                         "no committed PMC summary matches these kernel sources / this workload",
                          "copy_peak_GBps_measured_here": copy_peak,
-                         "kernel": "train_step pipeline (all launches of one step)",
+                         "kernel": "train_step pipeline (all launches of one step; BatchNorm's batch "
+                                   "statistics force the launches apart)",
                          "algorithmic_bytes_per_step": alg,
-                         "gpu_ms_per_step_hip_events": round(step_gpu_s * 1e3, 4)},
+                         "gpu_ms_per_step_hip_events": round(step_gpu_s * 1e3, 4),
+                         # every stage of the step, HIP events on the launch stream, microseconds;
+                         # with the fraction of the resource that binds it (this path is
+                         # ~600-900 FLOP/B: no kernel is HBM-bound on algorithmic bytes)
+                         "dominant_kernel": dominant,
+                         "kernels": kernels,
+                         "kernel_sum_us": round(sum(stage_us.values()), 1) if stage_us else None},
         }
         out["with_optimizer"] = None if args.skip_optimizer else {
             "ms_per_step": round(wall_opt / args.steps * 1e3, 4),
             "value": round(seqs / wall_opt, 1), "unit": "sequences/s",
             "optimizer": "Adam(lr=0.003), one fused launch (csrc/adam.hip)"}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
         if args.n_frac > 0:

@@ -47,6 +47,7 @@ EXPORTS = (
     "explainn_input_flags", "explainn_filter_act_max", "explainn_filter_sites",
     "explainn_pwm_scan", "explainn_stage_codes", "explainn_adam_step",
     "explainn_train_step_fc", "explainn_train_step_conv",
+    "explainn_stage_timing", "explainn_stage_count", "explainn_stage_name", "explainn_stage_times",
 )
 
 
@@ -117,6 +118,14 @@ def load():
     lib.explainn_adam_step.restype = C.c_int
     lib.explainn_pwm_scan.argtypes = [_fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp]
     lib.explainn_pwm_scan.restype = C.c_int
+    lib.explainn_stage_timing.argtypes = [ctx, C.c_int]
+    lib.explainn_stage_timing.restype = C.c_int
+    lib.explainn_stage_count.argtypes = []
+    lib.explainn_stage_count.restype = C.c_int
+    lib.explainn_stage_name.argtypes = [C.c_int]
+    lib.explainn_stage_name.restype = C.c_char_p
+    lib.explainn_stage_times.argtypes = [ctx, C.POINTER(C.c_float), C.c_int]
+    lib.explainn_stage_times.restype = C.c_int
     lib.explainn_input_flags.argtypes = [ctx, C.POINTER(C.c_int), _fp]
     lib.explainn_input_flags.restype = C.c_int
     _lib = lib
@@ -146,6 +155,16 @@ class Context:
         check(self.lib.explainn_create(C.byref(h), cnn_units, kernel_size, sequence_length,
                                        n_features, max_batch, device))
         self.handle = h
+
+    def stage_timing(self, enable=True):
+        check(self.lib.explainn_stage_timing(self.handle, int(bool(enable))))
+
+    def stage_times(self):
+        """{stage name: microseconds} of the last training step (device-synchronising)."""
+        n = self.lib.explainn_stage_count()
+        buf = (C.c_float * n)()
+        check(self.lib.explainn_stage_times(self.handle, buf, n))
+        return {self.lib.explainn_stage_name(i).decode(): float(buf[i]) for i in range(n) if buf[i] >= 0}
 
     def scratch_bytes(self):
         return int(self.lib.explainn_scratch_bytes(self.handle))

@@ -101,6 +101,18 @@ int check_batch(const explainn_ctx* c, int B) {
         if (rc_ != EXPLAINN_OK) return rc_; \
     } while (0)
 
+// Per-stage device times (explainn_stage_timing / explainn_stage_times): with timing on, every
+// stage of the training step is bracketed by two HIP events on the launch stream.
+const char* const kStageNames[ST_COUNT] = {
+    "pack_tables", "moments", "prep1_stats", "conv_pool", "qmom", "prep2", "fc_fwd", "head_fwd",
+    "loss", "head_bwd", "passA", "mid", "passB", "conv_bwd", "fin_bwd"};
+#define STAGE(id, call)                                                                 \
+    do {                                                                                \
+        if (c->timing) HIP_TRY(hipEventRecord(c->ev0[id], s));                          \
+        TRY(call);                                                                      \
+        if (c->timing) { HIP_TRY(hipEventRecord(c->ev1[id], s)); c->timed |= 1u << (id); } \
+    } while (0)
+
 int eval_front(explainn_ctx* c, const float* x, int B, const explainn_params* p, hipStream_t s) {
     // every eval-mode entry point overwrites scratch a pending backward would read (codes, ext,
     // idx, z, bits ...): whatever train forward was in flight is gone, and its backward must fail
@@ -199,9 +211,6 @@ extern "C" int explainn_create(explainn_ctx** out, int cnn_units, int kernel_siz
     // from here on every failure releases what was acquired (explainn_destroy copes with the
     // members that are still null)
     int rc = [&]() -> int {
-        HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->seed_ring), SEED_RING * 2 * sizeof(uint32_t), hipHostMallocDefault));
         TRY(prep_configure(c));
         TRY(bwd_configure(c));
@@ -216,9 +225,10 @@ extern "C" int explainn_create(explainn_ctx** out, int cnn_units, int kernel_siz
 
 extern "C" void explainn_destroy(explainn_ctx* c) {
     if (!c) return;
-    if (c->side) (void)hipStreamDestroy(c->side);
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    for (int i = 0; i < ST_COUNT; ++i) {
+        if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]);
+        if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
+    }
     if (c->graph_exec) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(c->graph_exec));
     if (c->seed_ring) (void)hipHostFree(c->seed_ring);
     if (c->base) (void)hipFree(c->base);
@@ -309,33 +319,22 @@ extern "C" int explainn_forward_train(explainn_ctx* c, const float* x, int B,
     c->eval_valid = false;             // the train-mode folds overwrite the eval-mode tables
     // the one-hot batch is packed and the filter tables are built by one launch; a staged batch of
     // base codes (x == NULL) is already packed and only needs the tables
-    if (x) TRY(launch_pack_tables(c, x, p, B, s));
+    if (x) STAGE(ST_PACK, launch_pack_tables(c, x, p, B, s));
     else {
         TRY(launch_pack(c, x, B, false, s));
-        TRY(launch_prep1_tables(c, p, s));
+        STAGE(ST_PACK, launch_prep1_tables(c, p, s));
     }
-    // The input-moment chain (bit masks -> Gram -> BatchNorm1 fold) needs only the packed codes, the
-    // filter bank only the filter tables and sign(gamma1).  Run in series they cost ~7 us before the
-    // filter bank; forked onto the side stream (EXPLAINN_FORK=1) they run beside it, but the filter
-    // bank fills every wave slot of the chip and the two stretch each other.
-    static const bool fork = [] { const char* e = getenv("EXPLAINN_FORK"); return e && e[0] == '1'; }();
-    if (fork) {
-        HIP_TRY(hipEventRecord(c->ev_fork, s));
-        HIP_TRY(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-        TRY(launch_moments(c, B, c->side));
-        TRY(launch_prep1(c, p, B, true, c->side));
-        HIP_TRY(hipEventRecord(c->ev_join, c->side));
-        TRY(launch_conv_pool(c, p, B, s));
-        HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
-    } else {
-        TRY(launch_moments(c, B, s));
-        TRY(launch_prep1(c, p, B, true, s));
-        TRY(launch_conv_pool(c, p, B, s));
-    }
-    TRY(launch_qmoments(c, B, s));
-    TRY(launch_prep2(c, p, B, true, s));
-    TRY(launch_fc_fwd(c, p, B, true, keep_mask, dropout_p, seed, s));
-    TRY(launch_head_fwd(c, p, B, true, logits, nullptr, s));
+    // input moments (bit masks -> Gram -> BatchNorm1 fold), then the filter bank.  (Round 1 forked the
+    // moment chain onto a side stream beside the filter bank; the filter bank fills every wave slot
+    // of the chip, the two stretched each other, and in series -- now that the chain takes 5 + 4 us
+    // -- the step is 4 us shorter.)
+    STAGE(ST_MOMENTS, launch_moments(c, B, s));
+    STAGE(ST_PREP1, launch_prep1(c, p, B, true, s));
+    STAGE(ST_CONV_POOL, launch_conv_pool(c, p, B, s));
+    STAGE(ST_QMOM, launch_qmoments(c, B, s));
+    STAGE(ST_PREP2, launch_prep2(c, p, B, true, s));
+    STAGE(ST_FC_FWD, launch_fc_fwd(c, p, B, true, keep_mask, dropout_p, seed, s));
+    STAGE(ST_HEAD_FWD, launch_head_fwd(c, p, B, true, logits, nullptr, s));
     c->fwd_B = B;
     return EXPLAINN_OK;
 }
@@ -346,16 +345,16 @@ namespace {
 // backward_conv then produces conv_w, conv_b, bn1_w, bn1_b
 int backward_fc(explainn_ctx* c, int B, const explainn_params* p, const explainn_grads* g,
                 hipStream_t s) {
-    TRY(launch_passA(c, B, s));
-    TRY(launch_mid_bwd(c, p, g, B, s));
+    STAGE(ST_PASSA, launch_passA(c, B, s));
+    STAGE(ST_MID, launch_mid_bwd(c, p, g, B, s));
     return EXPLAINN_OK;
 }
 
 int backward_conv(explainn_ctx* c, int B, const explainn_params* p, const explainn_grads* g,
                   int freeze_top_n_filters, hipStream_t s) {
-    TRY(launch_passB(c, B, s));
-    TRY(launch_conv_bwd(c, B, s));
-    TRY(launch_fin_bwd(c, p, g, B, freeze_top_n_filters, s));
+    STAGE(ST_PASSB, launch_passB(c, B, s));
+    STAGE(ST_CONV_BWD, launch_conv_bwd(c, B, s));
+    STAGE(ST_FIN, launch_fin_bwd(c, p, g, B, freeze_top_n_filters, s));
     return EXPLAINN_OK;
 }
 
@@ -376,7 +375,7 @@ extern "C" int explainn_backward(explainn_ctx* c, const float* dlogits, int B,
         return EXPLAINN_E_STATE;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    TRY(launch_head_bwd(c, p, g, dlogits, B, s));
+    STAGE(ST_HEAD_BWD, launch_head_bwd(c, p, g, dlogits, B, s));
     return backward_tail(c, B, p, g, freeze_top_n_filters, s);
 }
 
@@ -405,10 +404,10 @@ int train_step_front(explainn_ctx* c, const float* x, const float* targets, int 
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (c->T <= 4) {
         // few tasks: the loss gradient is recomputed inside the head backward (one launch less)
-        TRY(launch_head_bwd_fused_loss(c, p, g, loss_kind, logits, targets, loss_out, B, s));
+        STAGE(ST_HEAD_BWD, launch_head_bwd_fused_loss(c, p, g, loss_kind, logits, targets, loss_out, B, s));
     } else {
-        TRY(explainn_loss_grad(c, loss_kind, logits, targets, B, loss_out, c->dlogits, stream));
-        TRY(launch_head_bwd(c, p, g, c->dlogits, B, s));
+        STAGE(ST_LOSS, explainn_loss_grad(c, loss_kind, logits, targets, B, loss_out, c->dlogits, stream));
+        STAGE(ST_HEAD_BWD, launch_head_bwd(c, p, g, c->dlogits, B, s));
     }
     return backward_fc(c, B, p, g, s);
 }
@@ -535,6 +534,37 @@ extern "C" int explainn_train_step_conv(explainn_ctx* c, int B, const explainn_p
     }
     c->tail_B = 0;
     return backward_conv(c, B, p, g, freeze_top_n_filters, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int explainn_stage_timing(explainn_ctx* c, int enable) {
+    if (!c) { explainn_set_error("null context"); return EXPLAINN_E_ARG; }
+    if (enable && !c->ev0[0]) {
+        for (int i = 0; i < ST_COUNT; ++i) {
+            HIP_TRY(hipEventCreate(&c->ev0[i]));
+            HIP_TRY(hipEventCreate(&c->ev1[i]));
+        }
+    }
+    c->timing = enable != 0;
+    c->timed = 0;
+    return EXPLAINN_OK;
+}
+
+extern "C" int explainn_stage_count(void) { return ST_COUNT; }
+extern "C" const char* explainn_stage_name(int i) { return (i >= 0 && i < ST_COUNT) ? kStageNames[i] : ""; }
+
+extern "C" int explainn_stage_times(explainn_ctx* c, float* us, int cap) {
+    if (!c || !us || cap < ST_COUNT) { explainn_set_error("stage_times: need room for %d floats", ST_COUNT); return EXPLAINN_E_ARG; }
+    HIP_TRY(hipDeviceSynchronize());
+    for (int i = 0; i < ST_COUNT; ++i) {
+        us[i] = -1.f;                                   // stage did not run in the last step
+        if (c->timed & (1u << i)) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, c->ev0[i], c->ev1[i]));
+            us[i] = ms * 1e3f;
+        }
+    }
+    c->timed = 0;
+    return EXPLAINN_OK;
 }
 
 extern "C" int explainn_input_flags(explainn_ctx* c, int* flags_host, void* stream) {

@@ -27,8 +27,9 @@ struct explainn_ctx {
     int K4;               // 4*k
     int QCH;              // b-chunks of the q-moment kernel
     int ACH;              // b-chunks of passA
-    hipStream_t side;     // second stream: input-moment chain runs beside the filter bank
-    hipEvent_t ev_fork, ev_join;
+    // per-stage timing (explainn_stage_timing): events bracketing every stage of the training step
+    bool timing; unsigned timed;
+    hipEvent_t ev0[16], ev1[16];
     // ---- state of the step in flight ----
     int fwd_B;            // batch of the last train forward (0 = none)
     int tail_B;           // batch of a train_step_fc whose train_step_conv is still due (0 = none)
@@ -101,6 +102,11 @@ struct explainn_ctx {
     int* flags;           // [1]
     int* site_cnt;        // [U4][Bs]  sites per (unit, sequence) of the current batch (filter->PWM export)
     int* site_off;        // [U4][Bs]  their exclusive scan in sequence order, plus the running total
+};
+
+enum explainn_stage {
+    ST_PACK, ST_MOMENTS, ST_PREP1, ST_CONV_POOL, ST_QMOM, ST_PREP2, ST_FC_FWD, ST_HEAD_FWD, ST_LOSS,
+    ST_HEAD_BWD, ST_PASSA, ST_MID, ST_PASSB, ST_CONV_BWD, ST_FIN, ST_COUNT
 };
 
 // ---- error plumbing (api.hip) ----

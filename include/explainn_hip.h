@@ -204,6 +204,17 @@ int explainn_adam_step(int n_tensors, float* const* params, const float* const* 
  * writes the flags to *flags_host and clears them. */
 int explainn_input_flags(explainn_ctx* ctx, int* flags_host, void* stream);
 
+/* Measurement aid (bench.py's per-kernel roofline; the reference only logs steps per second,
+ * selene/__init__.py:296-304): with timing enabled every stage of the training step is bracketed
+ * by HIP events on the launch stream; explainn_stage_times synchronises the device and returns
+ * the microseconds of each stage of the LAST step (-1 for stages that did not run), in the order
+ * of explainn_stage_name(0 .. explainn_stage_count()-1).  Off by default: the events cost a few
+ * microseconds per stage. */
+int explainn_stage_timing(explainn_ctx* ctx, int enable);
+int explainn_stage_count(void);
+const char* explainn_stage_name(int i);
+int explainn_stage_times(explainn_ctx* ctx, float* us, int cap);
+
 #ifdef __cplusplus
 }
 #endif
