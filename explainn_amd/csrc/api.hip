@@ -77,6 +77,8 @@ void carve(explainn_ctx* c, Carver& cv) {
     cv.take(&c->S12p, U * fc_ng(c->NQ) * (Bs / 16) * 2);
     cv.take(&c->Dspp, U * (Bs / 64) * K4);
     cv.take(&c->dlogits, (int64_t)c->maxB * c->T);
+    cv.take(&c->evpart, (int64_t)64 * Bs * 8);
+    cv.take(&c->evcount, Bs / 64 + 64);
     cv.take(&c->flags, 64);
     cv.take(&c->seed_dev, 64);
     cv.take(&c->dlT, (int64_t)c->T * Bs);
@@ -216,6 +218,7 @@ extern "C" int explainn_create(explainn_ctx** out, int cnn_units, int kernel_siz
         TRY(bwd_configure(c));
         TRY(fc_configure(c));
         TRY(conv_configure(c));
+        TRY(eval_fused_configure(c));
         return EXPLAINN_OK;
     }();
     if (rc != EXPLAINN_OK) { explainn_destroy(c); return rc; }
@@ -242,6 +245,12 @@ extern "C" int explainn_forward_eval(explainn_ctx* c, const float* x, int B,
     TRY(check_batch(c, B));
     hipStream_t s = static_cast<hipStream_t>(stream);
     TRY(eval_front(c, x, B, p, s));
+    if (eval_fused_available(c)) {
+        // pack + ONE launch (few tasks), or + the combiner GEMM (many tasks)
+        TRY(launch_eval_fused(c, p, B, logits, false, s));
+        if (c->T > 8) TRY(launch_head_fwd(c, p, B, false, logits, nullptr, s));
+        return EXPLAINN_OK;
+    }
     TRY(launch_conv_pool(c, p, B, s));
     TRY(launch_fc_fwd(c, p, B, false, nullptr, 0.f, 0, s));
     TRY(launch_head_fwd(c, p, B, false, logits, nullptr, s));
@@ -253,8 +262,12 @@ extern "C" int explainn_unit_outputs(explainn_ctx* c, const float* x, int B,
     TRY(check_batch(c, B));
     hipStream_t s = static_cast<hipStream_t>(stream);
     TRY(eval_front(c, x, B, p, s));
-    TRY(launch_conv_pool(c, p, B, s));
-    TRY(launch_fc_fwd(c, p, B, false, nullptr, 0.f, 0, s));
+    if (eval_fused_available(c)) {
+        TRY(launch_eval_fused(c, p, B, nullptr, true, s));
+    } else {
+        TRY(launch_conv_pool(c, p, B, s));
+        TRY(launch_fc_fwd(c, p, B, false, nullptr, 0.f, 0, s));
+    }
     TRY(launch_head_fwd(c, p, B, false, nullptr, outs, s));
     return EXPLAINN_OK;
 }

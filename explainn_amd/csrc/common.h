@@ -99,6 +99,8 @@ struct explainn_ctx {
     // those of parameter version eval_version; a train-mode forward overwrites them
     bool eval_valid;
     uint64_t eval_version;
+    float* evpart;        // [64][Bs][8] per-unit-group partial logits of the fused eval kernel
+    int* evcount;         // [Bs/64]     arrival counters of its sequence tiles (zero between launches)
     int* flags;           // [1]
     int* site_cnt;        // [U4][Bs]  sites per (unit, sequence) of the current batch (filter->PWM export)
     int* site_off;        // [U4][Bs]  their exclusive scan in sequence order, plus the running total
@@ -159,6 +161,10 @@ int prep_configure(explainn_ctx* c);
 int bwd_configure(explainn_ctx* c);
 int fc_configure(explainn_ctx* c);
 int conv_configure(explainn_ctx* c);
+int eval_fused_configure(explainn_ctx* c);
+bool eval_fused_available(const explainn_ctx* c);
+int launch_eval_fused(explainn_ctx* c, const explainn_params* p, int B, float* logits, bool write_o,
+                      hipStream_t s);
 
 // In-kernel stamps (tools/stampbench.hip defines EXPLAINN_STAMP; the library build compiles them out)
 #ifdef EXPLAINN_STAMP

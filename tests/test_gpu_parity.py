@@ -665,3 +665,34 @@ def test_eval_tables_follow_parameter_changes():
     check("after load_state_dict")
     m.final.weight = torch.nn.Parameter(m.final.weight.detach() * 2)
     check("after re-assigning a Parameter")
+
+
+def test_single_launch_eval_kernel(monkeypatch):
+    """EXPLAINN_EVAL_FUSED=1: the eval forward as pack + ONE launch (filter bank -> pooling -> exp
+    -> FC -> combiner with the pooled activations in LDS, partial logits combined by the last
+    workgroup of each sequence tile).  Same numbers as the default path (bit for bit in the unit
+    outputs; logits to rounding: the combiner sums units in another order) and as the golden
+    vectors; deterministic from call to call."""
+    for name in ("small_u8_k19", "mid_u8_k19_L200", "tiny_u3_k5_N", "c1_u100_k19_L200"):
+        g = Golden(name)
+        m = _model(g.sd(), g.U, g.k, g.L, g.T).eval()
+        x = torch.from_numpy(g.onehot()).cuda()
+        with torch.no_grad():
+            monkeypatch.delenv("EXPLAINN_EVAL_FUSED", raising=False)
+            ref_logits, ref_outs = m(x), m.linears(x.repeat(1, g.U, 1))
+            monkeypatch.setenv("EXPLAINN_EVAL_FUSED", "1")
+            a, b = m(x), m(x)
+            outs = m.linears(x.repeat(1, g.U, 1))
+        assert torch.equal(a, b), name
+        assert torch.equal(outs, ref_outs), name
+        _close(_np(a), _np(ref_logits), tol=2e-6, what=name + " fused vs default logits")
+        _close(_np(a), g.z["eval/logits"], what=name + " fused eval logits")
+    monkeypatch.delenv("EXPLAINN_EVAL_FUSED", raising=False)
+    # many tasks: the kernel exports the unit outputs and the combiner GEMM follows
+    U, k, L, T, B = 37, 19, 61, 50, 70
+    sd = orc.random_state_dict(U, k, L, T, seed=U + L)
+    x = orc.random_onehot(B, L, seed=4, n_frac=0.02)
+    m = _model(sd, U, k, L, T).eval()
+    monkeypatch.setenv("EXPLAINN_EVAL_FUSED", "1")
+    with torch.no_grad():
+        _close(_np(m(torch.from_numpy(x).cuda())), orc.forward(sd, x), what="fused eval, T = 50")
