@@ -47,6 +47,7 @@ EXPORTS = (
     "explainn_input_flags", "explainn_filter_act_max", "explainn_filter_sites",
     "explainn_pwm_scan", "explainn_stage_codes", "explainn_adam_step",
     "explainn_train_step_fc", "explainn_train_step_conv",
+    "explainn_stage_onehot", "explainn_dense_input",
     "explainn_stage_timing", "explainn_stage_count", "explainn_stage_name", "explainn_stage_times",
 )
 
@@ -118,6 +119,10 @@ def load():
     lib.explainn_adam_step.restype = C.c_int
     lib.explainn_pwm_scan.argtypes = [_fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp]
     lib.explainn_pwm_scan.restype = C.c_int
+    lib.explainn_stage_onehot.argtypes = [ctx, _fp, C.c_int, _fp]
+    lib.explainn_stage_onehot.restype = C.c_int
+    lib.explainn_dense_input.argtypes = [ctx, C.c_int]
+    lib.explainn_dense_input.restype = C.c_int
     lib.explainn_stage_timing.argtypes = [ctx, C.c_int]
     lib.explainn_stage_timing.restype = C.c_int
     lib.explainn_stage_count.argtypes = []

@@ -144,6 +144,7 @@ class _Runtime:
         self.ctx = None
         self.token = 0
         self.pending = None
+        self.x_keep = None
 
     def __deepcopy__(self, memo):
         return _Runtime()
@@ -227,6 +228,9 @@ class ExplaiNN(_Model):
         self.final = nn.Linear(U, n_features)
         self.dropout_p = DROPOUT_P
         self.validate_input = True
+        # None: a batch that fails validation takes the dense kernels (the reference accepts any
+        # float input); True: always dense; False: a batch that is not one-hot is an error
+        self.dense_input = None
         self.grad_sync = None          # optional callable(flat_grad_tensor): multi-GPU all-reduce
         # rows [0:n) of the filter gradient are zeroed inside the backward kernel (what the hook of
         # selene/__init__.py:254-257, 509-515 does to the reference's gradient)
@@ -376,13 +380,38 @@ class ExplaiNN(_Model):
             raise RuntimeError("input is on %s but the model is on %s" % (x.device, dev))
         return x.detach().to(torch.float32).contiguous()
 
-    def _x_ptr(self, ctx, x, dev):
-        """Device pointer of the one-hot batch, or -- for base codes -- stage them in the context
-        and return NULL ("the staged batch", include/explainn_hip.h)."""
+    def _x_ptr(self, ctx, x, dev, validate=None):
+        """Device pointer of the batch as the C ABI wants it: base codes are staged in the context
+        and NULL ("the staged batch", include/explainn_hip.h) is returned.  An fp32 batch is, when
+        input validation is on, staged too and its validation flag read BEFORE anything is
+        computed from it: a batch that is not one-hot (the reference accepts any float tensor,
+        architectures/__init__.py:111) goes through the dense kernels instead of being run as if
+        its soft columns were N -- unless dense_input is False, which keeps the strict error."""
+        lib, h, stream = ctx.lib, ctx.handle, self._stream(dev)
         if isinstance(x, BaseCodes):
-            _lib.check(ctx.lib.explainn_stage_codes(ctx.handle, x.codes.data_ptr(), x.codes.shape[0],
-                                                    int(x.reverse_complement), self._stream(dev)))
+            _lib.check(lib.explainn_dense_input(h, 0))
+            _lib.check(lib.explainn_stage_codes(h, x.codes.data_ptr(), x.codes.shape[0],
+                                                int(x.reverse_complement), stream))
             return None
+        if self.dense_input:
+            _lib.check(lib.explainn_dense_input(h, 1))
+            self._rt.x_keep = x
+            return x.data_ptr()
+        if self.validate_input if validate is None else validate:
+            _lib.check(lib.explainn_stage_onehot(h, x.data_ptr(), x.shape[0], stream))
+            flags = C.c_int(0)
+            _lib.check(lib.explainn_input_flags(h, C.byref(flags), stream))
+            if flags.value & 1:
+                if self.dense_input is False:
+                    raise ValueError(
+                        "input is not one-hot: every column of x must be one-hot (A,C,G,T) or all-zero "
+                        "(N) as sequence.one_hot_encode produces (dense_input=False forbids the dense path)")
+                _lib.check(lib.explainn_dense_input(h, 1))
+                self._rt.x_keep = x            # the backward of a train forward reads x again
+                return x.data_ptr()
+            _lib.check(lib.explainn_dense_input(h, 0))
+            return None
+        _lib.check(lib.explainn_dense_input(h, 0))
         return x.data_ptr()
 
     def _stream(self, dev):
@@ -395,8 +424,8 @@ class ExplaiNN(_Model):
         _lib.check(ctx.lib.explainn_input_flags(ctx.handle, C.byref(flags), self._stream(dev)))
         if flags.value & 1:
             raise ValueError(
-                "input is not one-hot: every column of x must be one-hot (A,C,G,T) or all-zero "
-                "(N) as sequence.one_hot_encode produces; soft inputs are not supported")
+                "input is not one-hot: base codes must be 0..4, and every column of an fp32 x must "
+                "be one-hot (A,C,G,T) or all-zero (N) as sequence.one_hot_encode produces")
 
     def input_flags(self):
         """Synchronise and return (then clear) the device-side input validation flags."""

@@ -120,7 +120,12 @@ int eval_front(explainn_ctx* c, const float* x, int B, const explainn_params* p,
     // idx, z, bits ...): whatever train forward was in flight is gone, and its backward must fail
     // with E_STATE instead of returning the eval batch's gradients
     c->fwd_B = 0; c->tail_B = 0;
-    TRY(launch_pack(c, x, B, false, s));
+    if (c->dense) {
+        if (!x) { explainn_set_error("dense input mode needs x"); return EXPLAINN_E_ARG; }
+        c->staged_B = 0;
+    } else {
+        TRY(launch_pack(c, x, B, false, s));
+    }
     // The folded tables depend on the parameters only: rebuilt when the caller's parameter version
     // moved (or is unknown), not per batch -- predict.py's loop and a validation pass run pack +
     // filter bank + FC + head per batch and nothing else.
@@ -245,6 +250,12 @@ extern "C" int explainn_forward_eval(explainn_ctx* c, const float* x, int B,
     TRY(check_batch(c, B));
     hipStream_t s = static_cast<hipStream_t>(stream);
     TRY(eval_front(c, x, B, p, s));
+    if (c->dense) {
+        TRY(launch_dense_conv_pool(c, x, p, B, s));
+        TRY(launch_fc_fwd(c, p, B, false, nullptr, 0.f, 0, s));
+        TRY(launch_head_fwd(c, p, B, false, logits, nullptr, s));
+        return EXPLAINN_OK;
+    }
     if (eval_fused_available(c)) {
         // pack + ONE launch (few tasks), or + the combiner GEMM (many tasks)
         TRY(launch_eval_fused(c, p, B, logits, false, s));
@@ -262,7 +273,10 @@ extern "C" int explainn_unit_outputs(explainn_ctx* c, const float* x, int B,
     TRY(check_batch(c, B));
     hipStream_t s = static_cast<hipStream_t>(stream);
     TRY(eval_front(c, x, B, p, s));
-    if (eval_fused_available(c)) {
+    if (c->dense) {
+        TRY(launch_dense_conv_pool(c, x, p, B, s));
+        TRY(launch_fc_fwd(c, p, B, false, nullptr, 0.f, 0, s));
+    } else if (eval_fused_available(c)) {
         TRY(launch_eval_fused(c, p, B, nullptr, true, s));
     } else {
         TRY(launch_conv_pool(c, p, B, s));
@@ -277,6 +291,7 @@ extern "C" int explainn_unit_activations(explainn_ctx* c, const float* x, int B,
     TRY(check_batch(c, B));
     hipStream_t s = static_cast<hipStream_t>(stream);
     TRY(eval_front(c, x, B, p, s));
+    if (c->dense) return launch_dense_conv_act(c, x, B, acts, s);
     TRY(launch_conv_act(c, B, acts, s));
     return EXPLAINN_OK;
 }
@@ -294,6 +309,7 @@ extern "C" int explainn_filter_act_max(explainn_ctx* c, const float* x, int B,
                                        float* unit_max, void* stream) {
     TRY(check_batch(c, B));
     if (!unit_max) { explainn_set_error("unit_max is null"); return EXPLAINN_E_ARG; }
+    if (c->dense) { explainn_set_error("the filter export works on base codes: one-hot input only"); return EXPLAINN_E_UNSUPPORTED; }
     hipStream_t s = static_cast<hipStream_t>(stream);
     TRY(eval_front(c, x, B, p, s));
     return launch_filter_act_max(c, B, select, unit_max, s);
@@ -308,6 +324,7 @@ extern "C" int explainn_filter_sites(explainn_ctx* c, const float* x, int B, con
         return EXPLAINN_E_ARG;
     }
     if (site_cap <= 0) { explainn_set_error("site_cap must be positive"); return EXPLAINN_E_ARG; }
+    if (c->dense) { explainn_set_error("the filter export works on base codes: one-hot input only"); return EXPLAINN_E_UNSUPPORTED; }
     hipStream_t s = static_cast<hipStream_t>(stream);
     TRY(eval_front(c, x, B, p, s));
     return launch_filter_sites(c, B, select, thresholds, site_cap, site_total, pfm, hit, s);
@@ -332,6 +349,17 @@ extern "C" int explainn_forward_train(explainn_ctx* c, const float* x, int B,
     c->eval_valid = false;             // the train-mode folds overwrite the eval-mode tables
     // the one-hot batch is packed and the filter tables are built by one launch; a staged batch of
     // base codes (x == NULL) is already packed and only needs the tables
+    c->dense_x = nullptr;
+    if (c->dense) {
+        // soft input: no codes to pack; the stages that touch x take the dense kernels (dense.hip)
+        if (!x) { explainn_set_error("dense input mode needs x"); return EXPLAINN_E_ARG; }
+        c->staged_B = 0;
+        STAGE(ST_PACK, launch_prep1_tables(c, p, s));
+        STAGE(ST_MOMENTS, launch_dense_moments(c, x, B, s));
+        STAGE(ST_PREP1, launch_prep1(c, p, B, true, s));
+        STAGE(ST_CONV_POOL, launch_dense_conv_pool(c, x, p, B, s));
+        c->dense_x = x;
+    } else {
     if (x) STAGE(ST_PACK, launch_pack_tables(c, x, p, B, s));
     else {
         TRY(launch_pack(c, x, B, false, s));
@@ -344,6 +372,7 @@ extern "C" int explainn_forward_train(explainn_ctx* c, const float* x, int B,
     STAGE(ST_MOMENTS, launch_moments(c, B, s));
     STAGE(ST_PREP1, launch_prep1(c, p, B, true, s));
     STAGE(ST_CONV_POOL, launch_conv_pool(c, p, B, s));
+    }
     STAGE(ST_QMOM, launch_qmoments(c, B, s));
     STAGE(ST_PREP2, launch_prep2(c, p, B, true, s));
     STAGE(ST_FC_FWD, launch_fc_fwd(c, p, B, true, keep_mask, dropout_p, seed, s));
@@ -366,7 +395,8 @@ int backward_fc(explainn_ctx* c, int B, const explainn_params* p, const explainn
 int backward_conv(explainn_ctx* c, int B, const explainn_params* p, const explainn_grads* g,
                   int freeze_top_n_filters, hipStream_t s) {
     STAGE(ST_PASSB, launch_passB(c, B, s));
-    STAGE(ST_CONV_BWD, launch_conv_bwd(c, B, s));
+    if (c->dense_x) STAGE(ST_CONV_BWD, launch_dense_conv_bwd(c, c->dense_x, B, s));
+    else STAGE(ST_CONV_BWD, launch_conv_bwd(c, B, s));
     STAGE(ST_FIN, launch_fin_bwd(c, p, g, B, freeze_top_n_filters, s));
     return EXPLAINN_OK;
 }
@@ -471,7 +501,7 @@ extern "C" int explainn_train_step(explainn_ctx* c, const float* x, const float*
     static_assert(sizeof(step_key) <= sizeof(c->graph_key), "graph key buffer too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
     // stream 0 (the legacy default stream) cannot be captured; staged base codes change per call
-    const bool eligible = graphs_enabled() && c && x && p && g && s != nullptr && B > 1;
+    const bool eligible = graphs_enabled() && c && x && p && g && s != nullptr && B > 1 && !c->dense;
     if (!eligible)
         return step_direct(c, x, targets, B, p, g, loss_kind, dropout_p, seed, freeze_top_n_filters,
                            logits, loss_out, stream);
@@ -547,6 +577,23 @@ extern "C" int explainn_train_step_conv(explainn_ctx* c, int B, const explainn_p
     }
     c->tail_B = 0;
     return backward_conv(c, B, p, g, freeze_top_n_filters, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int explainn_dense_input(explainn_ctx* c, int enable) {
+    if (!c) { explainn_set_error("null context"); return EXPLAINN_E_ARG; }
+    c->dense = enable != 0;
+    c->fwd_B = 0; c->tail_B = 0;
+    return EXPLAINN_OK;
+}
+
+extern "C" int explainn_stage_onehot(explainn_ctx* c, const float* x, int B, void* stream) {
+    TRY(check_batch(c, B));
+    if (!x) { explainn_set_error("x is null"); return EXPLAINN_E_ARG; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    c->fwd_B = 0; c->tail_B = 0;        // the packed codes of a pending backward are overwritten
+    TRY(launch_pack(c, x, B, true, s));  // with the bit masks: the batch may feed a train forward
+    c->staged_B = B;
+    return EXPLAINN_OK;
 }
 
 extern "C" int explainn_stage_timing(explainn_ctx* c, int enable) {

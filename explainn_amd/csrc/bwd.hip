@@ -15,7 +15,6 @@
 typedef float f32x16b __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4b __attribute__((ext_vector_type(4)));
-#define CB_TILES 2           // 64-sequence tiles per conv_bwd wavefront
 #define CB_PF 4              // pooling windows whose dy / idx a conv_bwd lane fetches per batch
 
 // Register budget: this kernel must stay at <= 64 VGPRs so that TWO 1024-thread blocks share a CU --

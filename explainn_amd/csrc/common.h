@@ -17,6 +17,7 @@
 #define WAVE 64
 #define MAX_K 32          // kernel sizes instantiated for the conv kernels
 #define MAX_NQ 160        // largest pooled length with an instantiated FC kernel
+#define CB_TILES 2        // 64-sequence tiles per conv_bwd wavefront (one Dspp partial per CB_TILES tiles)
 
 struct explainn_ctx {
     int U, k, L, T, maxB, device;
@@ -99,6 +100,9 @@ struct explainn_ctx {
     // those of parameter version eval_version; a train-mode forward overwrites them
     bool eval_valid;
     uint64_t eval_version;
+    // soft (not one-hot) input: explainn_dense_input switches the stages that touch x to dense.hip
+    bool dense;
+    const float* dense_x;  // x of the train forward in flight (its backward reads it again)
     float* evpart;        // [64][Bs][8] per-unit-group partial logits of the fused eval kernel
     int* evcount;         // [Bs/64]     arrival counters of its sequence tiles (zero between launches)
     int* flags;           // [1]
@@ -156,6 +160,11 @@ int launch_passB(explainn_ctx* c, int B, hipStream_t s);
 int launch_conv_bwd(explainn_ctx* c, int B, hipStream_t s);
 int launch_fin_bwd(explainn_ctx* c, const explainn_params* p, const explainn_grads* g, int B,
                    int freeze_n, hipStream_t s);
+
+int launch_dense_moments(explainn_ctx* c, const float* x, int B, hipStream_t s);
+int launch_dense_conv_pool(explainn_ctx* c, const float* x, const explainn_params* p, int B, hipStream_t s);
+int launch_dense_conv_bwd(explainn_ctx* c, const float* x, int B, hipStream_t s);
+int launch_dense_conv_act(explainn_ctx* c, const float* x, int B, float* acts, hipStream_t s);
 
 int prep_configure(explainn_ctx* c);
 int bwd_configure(explainn_ctx* c);

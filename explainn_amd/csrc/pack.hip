@@ -212,8 +212,7 @@ __global__ __launch_bounds__(256) void moments_kernel(const unsigned long long* 
     }
 }
 
-int launch_moments(explainn_ctx* c, int B, hipStream_t s);
-
+// counts: also write the bit masks the moment kernel reads (train mode)
 int launch_pack(explainn_ctx* c, const float* x, int B, bool counts, hipStream_t s) {
     const int gb = (B + 63) / 64;
     if (x == nullptr) {
@@ -231,7 +230,6 @@ int launch_pack(explainn_ctx* c, const float* x, int B, bool counts, hipStream_t
                            c->Bs, c->PW, c->NW, c->flags, counts ? c->bm : nullptr, c->Lp);
         LAUNCH_CHECK();
     }
-    if (counts) return launch_moments(c, B, s);
     return EXPLAINN_OK;
 }
 

@@ -73,7 +73,7 @@ class StepEngine:
         if not (torch.is_tensor(x) and x.dtype == torch.float32):
             x = m._prep_input(x, self.dev)
         stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
-        xp = m._x_ptr(self.ctx, x, self.dev)
+        xp = m._x_ptr(self.ctx, x, self.dev, validate=False)   # the Trainer reads the sticky flag periodically
         if grad_sync is None:
             _lib.check(self.ctx.lib.explainn_train_step(
                 self.ctx.handle, xp, y.data_ptr(), B, C.byref(self.ps), C.byref(self.gs),

@@ -181,6 +181,21 @@ int explainn_filter_sites(explainn_ctx* ctx, const float* x, int B, const explai
 int explainn_stage_codes(explainn_ctx* ctx, const uint8_t* codes, int B, int reverse_complement,
                          void* stream);
 
+/* The fp32 one-hot packed into the context ahead of the forward: like explainn_stage_codes, the
+ * entry points then take x == NULL.  Lets the caller read explainn_input_flags BEFORE anything
+ * depends on the batch -- and route a batch that is not one-hot to the dense kernels (next entry)
+ * instead of running it as if its soft columns were N. */
+int explainn_stage_onehot(explainn_ctx* ctx, const float* x, int B, void* stream);
+
+/* Soft inputs.  The reference's forward takes ANY float (B,4,L) tensor (architectures/__init__.py:111
+ * feeds x to a grouped Conv1d); the fast path here needs one-hot columns.  enable != 0 makes every
+ * following entry point read x as a general dense tensor (csrc/dense.hip: dense input moments,
+ * dense filter bank + pooling, dense filter-gradient scatter, dense activations; everything behind
+ * the pooled activations is the regular pipeline) -- same results, to rounding, as the fast path
+ * gives on one-hot x.  x must stay valid until the backward of a train forward has been enqueued.
+ * The filter -> PWM export (explainn_filter_*) has no dense form: EXPLAINN_E_UNSUPPORTED. */
+int explainn_dense_input(explainn_ctx* ctx, int enable);
+
 /* PWM scan: the reference's `PWM` module forward (architectures/__init__.py:157-168).
  * x: fp32 (B,4,L) rows A,C,G,T; pwms: fp32 (G,4,k); scores: fp32 (B,G) = max (EXPLAINN_PWM_MAX) or
  * sum (EXPLAINN_PWM_SUM) of the window scores over both strands.  No context needed. */

@@ -358,15 +358,54 @@ def test_batch_of_one_in_train_mode_raises():
         m(torch.from_numpy(orc.random_onehot(1, 26)).cuda())
 
 
-def test_non_one_hot_input_is_rejected():
-    sd = orc.random_state_dict(2, 5, 26, 1)
-    m = _model(sd, 2, 5, 26, 1).eval()
-    x = torch.from_numpy(orc.random_onehot(4, 26)).cuda()
-    x[1, :, 3] = 0.25
+def test_soft_input_takes_the_dense_path():
+    """The reference's forward accepts any float (B,4,L) tensor (architectures/__init__.py:111).  A
+    batch that is not one-hot is detected before anything is computed from it and runs through
+    csrc/dense.hip: eval logits, unit outputs, per-position activations, and a full train step
+    (logits, loss, all 14 gradients, BatchNorm buffers) against the oracle on a soft input (a
+    position-probability blend, one all-zero sequence, one exactly one-hot sequence)."""
+    U, k, L, T, B = 5, 9, 47, 2, 20
+    sd = orc.random_state_dict(U, k, L, T, seed=81)
+    sd["linears.1.weight"][::2] *= -1
+    rng = np.random.default_rng(82)
+    x = rng.dirichlet(np.ones(4) * 0.3, size=(B, L)).transpose(0, 2, 1).astype(np.float32)
+    x[0] = 0
+    x[1] = orc.random_onehot(1, L, seed=83)[0]
+    x = np.ascontiguousarray(x)
+    xt = torch.from_numpy(x).cuda()
+    m = _model(sd, U, k, L, T).eval()
+    with torch.no_grad():
+        _close(_np(m(xt)), orc.forward(sd, x), what="soft eval logits")
+        _close(_np(m.linears(xt.repeat(1, U, 1))), orc.unit_outputs(sd, x), what="soft unit outputs")
+        _close(_np(m.linears[:3](xt.repeat(1, U, 1))), orc.unit_activations(sd, x), what="soft activations")
+        # a one-hot batch right after takes the fast path again, with the same context
+        xo = orc.random_onehot(B, L, seed=84, n_frac=0.02)
+        _close(_np(m(torch.from_numpy(xo).cuda())), orc.forward(sd, xo), what="one-hot after soft")
+    y = (rng.random((B, T)) > 0.5).astype(np.float32)
+    ref_logits, ref_loss, ref_grads, nb = _oracle_step(sd, x, y)
+    m = _model(sd, U, k, L, T).train()
+    m.dropout_p = 0.0
+    logits = m(xt)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, torch.from_numpy(y).cuda())
+    loss.backward()
+    _close(_np(logits), ref_logits, what="soft train logits")
+    _close(loss.item(), ref_loss, tol=1e-5, what="loss")
+    _check_grads([(key, p.grad) for key, p in m.named_parameters()], ref_grads, "soft ")
+    bufs = dict(m.named_buffers())
+    for key, v in nb.items():
+        if "tracked" not in key:
+            _close(_np(bufs[key]), v, what=key)
+    # dense_input=True sends a ONE-HOT batch down the dense kernels too: same numbers as the fast path
+    m2 = _model(sd, U, k, L, T).eval()
+    m2.dense_input = True
+    with torch.no_grad():
+        _close(_np(m2(torch.from_numpy(xo).cuda())), orc.forward(sd, xo), what="one-hot via dense kernels")
+    # dense_input=False keeps the strict behaviour
+    m3 = _model(sd, U, k, L, T).eval()
+    m3.dense_input = False
     with pytest.raises(ValueError, match="not one-hot"):
-        m(x)
-    x = torch.from_numpy(orc.random_onehot(4, 26)).cuda()
-    m(x)                                    # the flag was cleared; clean input passes
+        m3(xt)
+    m3(torch.from_numpy(xo).cuda())
 
 
 def test_builtin_dropout_rate_and_scaling():
@@ -466,12 +505,16 @@ def test_base_codes_errors():
         m(bad)
     with pytest.raises(RuntimeError):
         m(torch.zeros(4, g.L + 1, dtype=torch.uint8).cuda())    # wrong length
-    # x == NULL without staged codes is a state error, not a crash
-    ctx = m._context(4, m._device())
-    ps, keep = m._params_struct(m._device())
+    # x == NULL without a staged batch is a state error, not a crash
+    m2 = _model(g.sd(), g.U, g.k, g.L, g.T).eval()
+    ctx = m2._context(4, m2._device())
+    ps, keep = m2._params_struct(m2._device())
     out = torch.empty(4, g.T).cuda()
     import ctypes
-    m(torch.from_numpy(g.onehot()[:4]).cuda())                  # a real x discards staged codes
+    rc = ctx.lib.explainn_forward_eval(ctx.handle, None, 4, ctypes.byref(ps), out.data_ptr(), None)
+    assert rc == _lib.E_STATE
+    # ... and so is a staged batch of another size
+    m2(torch.from_numpy(g.onehot()[:3]).cuda())
     rc = ctx.lib.explainn_forward_eval(ctx.handle, None, 4, ctypes.byref(ps), out.data_ptr(), None)
     assert rc == _lib.E_STATE
 
