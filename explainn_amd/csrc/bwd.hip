@@ -162,7 +162,19 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
             g_fc1_w[ch * n + w] = (float)val;
         }
         Tt[ch * NS + w] = tv;
-        Ttf[(((size_t)u * NW16 + (w >> 4)) * (FC_H / 4) + (r >> 2)) * 64 + 16 * (r & 3) + (w & 15)] = tv;
+        {
+            // T[r][w] as three bf16 pieces (hi + mid + lo = tv exactly) in the A-fragment order of
+            // v_mfma_f32_16x16x32_bf16: lane 16((r>>3)&3) + (w&15), element r&7 of k-step r>>5
+            const uint32_t hb = __float_as_uint(tv) & 0xffff0000u;
+            const float r1 = tv - __uint_as_float(hb);
+            const uint32_t mb = __float_as_uint(r1) & 0xffff0000u;
+            const float r2 = r1 - __uint_as_float(mb);
+            uint16_t* tb = reinterpret_cast<uint16_t*>(Ttf) + ((size_t)u * NW16 + (w >> 4)) * (3 * 4 * 512) +
+                           ((size_t)(r >> 5) * 64 + 16 * ((r >> 3) & 3) + (w & 15)) * 8 + (r & 7);
+            tb[0] = (uint16_t)(hb >> 16);
+            tb[4 * 512] = (uint16_t)(mb >> 16);
+            tb[8 * 512] = (uint16_t)(__float_as_uint(r2) >> 16);
+        }
     }
     __syncthreads();
     STAMP(4);
@@ -313,7 +325,19 @@ __global__ __launch_bounds__(1024) void mid_big_kernel(
             g_fc1_w[ch * n + w] = (float)val;
         }
         Tt[ch * NS + w] = tv;
-        Ttf[(((size_t)u * NW16 + (w >> 4)) * (FC_H / 4) + (r >> 2)) * 64 + 16 * (r & 3) + (w & 15)] = tv;
+        {
+            // T[r][w] as three bf16 pieces (hi + mid + lo = tv exactly) in the A-fragment order of
+            // v_mfma_f32_16x16x32_bf16: lane 16((r>>3)&3) + (w&15), element r&7 of k-step r>>5
+            const uint32_t hb = __float_as_uint(tv) & 0xffff0000u;
+            const float r1 = tv - __uint_as_float(hb);
+            const uint32_t mb = __float_as_uint(r1) & 0xffff0000u;
+            const float r2 = r1 - __uint_as_float(mb);
+            uint16_t* tb = reinterpret_cast<uint16_t*>(Ttf) + ((size_t)u * NW16 + (w >> 4)) * (3 * 4 * 512) +
+                           ((size_t)(r >> 5) * 64 + 16 * ((r >> 3) & 3) + (w & 15)) * 8 + (r & 7);
+            tb[0] = (uint16_t)(hb >> 16);
+            tb[4 * 512] = (uint16_t)(mb >> 16);
+            tb[8 * 512] = (uint16_t)(__float_as_uint(r2) >> 16);
+        }
     }
     for (int w = tid; w < NS; w += NT) {
         double k0 = 0;

@@ -75,7 +75,8 @@ struct explainn_ctx {
     float* Sep;           // [U][ACH][100]
     float* EQs;           // [U][100][NS]
     float* Tt;            // [U][100][NS]
-    float* Ttf;           // [U][NW16][25][64]     T in MFMA 16x16x4 A-fragment order (passB copies it to LDS)
+    float* Ttf;           // [U][NW16][3][4][64][8] bf16: T as three bf16 pieces in the A-fragment order of
+                          //                        v_mfma_f32_16x16x32_bf16 (passB copies it to LDS)
     float* Mff;           // [U][NW16][4 NW16][64] M in A-fragment order, k order (j',i') -> v = 16j'+4g+i' 
     float* M;             // [U][NS][NS]
     float* k0p;           // [U][NS]

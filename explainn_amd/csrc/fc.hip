@@ -19,9 +19,11 @@
 //            sequence are merged with two cross-group shuffles.  Nothing of size (B,100U) is stored.
 //   passA    D[r][w] = sum_b e[b][r] q[b][w],  e = dz[b]*bit[b][r] built on the fly from the bit
 //            words (A operand), q rows from a wave-private LDS tile (B operand); K = sequences.
-//   passB    D[w][b] = sum_r T[r][w] e[b][r] - sum_v M[v][w] q[b][v] - k0'[w]; then dy = dq*q and
-//            the two BatchNorm1-backward sums.  A = T and M fragments in LDS.  The k order of the
-//            M.q product is chosen so that a lane's q operands ARE the q values of its D rows.
+//   passB    D[w][b] = dz[b] sum_r T[r][w] bit[b][r] - sum_v M[v][w] q[b][v] - k0'[w]; then dy = dq*q
+//            and the two BatchNorm1-backward sums.  A = T (bf16 pieces) and M fragments in LDS.  The k
+//            order of the M.q product is chosen so that a lane's q operands ARE the q values of its D rows.
+//   passA / the T.bit part of passB have a BIT matrix as one operand: they run on the bf16 matrix
+//   core with the real operand split exactly into three bf16 pieces (see passA).
 //   qmom     (prep.hip) the q second-moment matrix.
 //
 // Template parameter NQ >= n (bucketed pooled length).
@@ -251,14 +253,32 @@ int launch_fc_fwd(explainn_ctx* c, const explainn_params* p, int B, bool train,
 }
 
 // ---------------------------------------------------------------------------------------------
-// passA: one wavefront per (unit, batch chunk, group of w tiles); K dimension = sequences, four
-// per MFMA.  Super-tiles of 64 sequences are fetched with coalesced loads (lane = sequence): the q
-// rows (from ext, through exp), the bit words and dz; they are re-read from a wave-private LDS
-// tile in MFMA operand order while the next super-tile's loads are already in flight.  The row
-// stride 68 makes the operand reads conflict-free: bank = (4 row + column) mod 64 with 16 rows x 4
-// columns per read.
+// passA: EQ[r][w] = sum_b e[b][r] q[b][w] with e[b][r] = dz[b] * bit[b][r], and Se[r] = sum_b e[b][r].
+// One wavefront per (unit, batch chunk, group of w tiles); K dimension = sequences.
+//
+// One operand of this product is a BIT matrix.  Written as  EQ = bit^T . X  with X[b][w] = dz[b] q[b][w]
+// (and one extra column X[b][n] = dz[b], which makes Se the (n+1)-th column of the same product), the
+// bits are exact in bf16 (0.0 / 1.0) and X is exact as the sum of three bf16 pieces (hi = the top 16
+// bits of the float, mid = the top 16 bits of x - hi, lo = x - hi - mid: 8 + 8 + 8 significant
+// bits).  Every product bit * piece is exact and the matrix core accumulates in fp32: the result is
+// an fp32 dot product, at 3/16 of the fp32-MFMA cost (v_mfma_f32_16x16x32_bf16: 32 sequences per
+// instruction at 16 cycles against 4 at 32).  Round 1/2a ran this on v_mfma_f32_32x32x2 / 16x16x4 and
+// was MFMA-pipe-bound at 38 us (C2).
+//
+// Super-tiles of 64 sequences are fetched with coalesced loads (lane = sequence): the q rows (from
+// ext, through exp), the bit words and dz.  X is split and written to a wave-private LDS image
+// [piece][w][sequence] (row stride 144 B: the 16-byte operand reads of 16 rows fall on distinct
+// banks); the bit operand A[r][k = sequence] is assembled from the per-sequence bit words, eight
+// 4-byte LDS reads per (channel-tile pair, 32 sequences), most of them broadcasts.  The next
+// super-tile's loads are in flight during the MFMAs.
 // ---------------------------------------------------------------------------------------------
-#define QA_LD 66
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+#define PA_LD 72                     // bf16 elements per row of the X image (64 sequences + 8 pad)
+__host__ __device__ constexpr int pa_nw16(int NQ) { return (NQ + 1 + 15) / 16; }   // + the dz column
+__host__ __device__ constexpr int pa_wgt(int NQ) { return pa_nw16(NQ) <= 2 ? pa_nw16(NQ) : 3; }
+__host__ __device__ constexpr int pa_ng(int NQ) { return (pa_nw16(NQ) + pa_wgt(NQ) - 1) / pa_wgt(NQ); }
+
 template <int NQ>
 __global__ __launch_bounds__(64) void passA_kernel(const float* __restrict__ ext,
                                                    const float* __restrict__ alpha,
@@ -268,13 +288,12 @@ __global__ __launch_bounds__(64) void passA_kernel(const float* __restrict__ ext
                                                    float* __restrict__ EQp,
                                                    float* __restrict__ Sep, int n, int Bs, int B,
                                                    int ACH) {
-    constexpr int NS = ns_stride(NQ), NW16 = fc_nw16(NQ), WGT = fc_wgt(NQ), ROWS = 16 * WGT;
-    __shared__ float tq[ROWS * QA_LD];
-    __shared__ __attribute__((aligned(16))) uint4 tw[64];
-    __shared__ float tdz[64];
+    constexpr int NS = ns_stride(NQ), WGT = pa_wgt(NQ), ROWS = 16 * WGT;
+    __shared__ __attribute__((aligned(16))) uint16_t xt[3 * ROWS * PA_LD];     // [piece][row][sequence] bf16
+    __shared__ __attribute__((aligned(16))) uint32_t tw[64 * 4];               // [sequence][4] bit words
     const int u = blockIdx.y, ch = blockIdx.x, grp = blockIdx.z, lane = threadIdx.x;
     const int c = lane & 15, g = lane >> 4;
-    const int w0 = grp * ROWS;                         // first pooled position of this group
+    const int w0 = grp * ROWS;                         // first column of this group
     const int per = ((((B + ACH - 1) / ACH) + 63) / 64) * 64;
     const int bbeg = ch * per, bend = min(B, bbeg + per);
     const float a1 = alpha[u], sh1 = shift[u];
@@ -288,9 +307,6 @@ __global__ __launch_bounds__(64) void passA_kernel(const float* __restrict__ ext
         for (int j = 0; j < WGT; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[t][j][i] = 0.f;
-    float se[FC_MT];
-#pragma unroll
-    for (int t = 0; t < FC_MT; ++t) se[t] = 0.f;
     float rq[ROWS], rdz = 0.f;
     uint4 rw = make_uint4(0u, 0u, 0u, 0u);
     auto fetch = [&](int b0) {
@@ -304,73 +320,95 @@ __global__ __launch_bounds__(64) void passA_kernel(const float* __restrict__ ext
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) KEEP(rq[i]);
         KEEP(rdz);
-#pragma unroll
-        for (int i = 0; i < ROWS; ++i) rq[i] = (live && w0 + i < n) ? qval(a1, rq[i], sh1) : 0.f;
         rdz = live ? rdz : 0.f;
+        // X[b][w] = dz q (w < n), dz (w == n: the Se column), 0 beyond
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) {
+            const int w = w0 + i;
+            rq[i] = w < n ? rdz * qval(a1, rq[i], sh1) : (w == n ? rdz : 0.f);
+        }
     };
     STAMP(0);
     if (bbeg < bend) fetch(bbeg);
     for (int b0 = bbeg; b0 < bend; b0 += 64) {
+        // three bf16 pieces of every X value into the LDS image (the store takes the upper half of
+        // the register)
 #pragma unroll
-        for (int i = 0; i < ROWS; ++i) tq[i * QA_LD + lane] = rq[i];
-        tw[lane] = rw;
-        tdz[lane] = rdz;
+        for (int i = 0; i < ROWS; ++i) {
+            const float x = rq[i];
+            const uint32_t hb = __float_as_uint(x) & 0xffff0000u;
+            const float r1 = x - __uint_as_float(hb);
+            const uint32_t mb = __float_as_uint(r1) & 0xffff0000u;
+            const float r2 = r1 - __uint_as_float(mb);
+            xt[(0 * ROWS + i) * PA_LD + lane] = (uint16_t)(hb >> 16);
+            xt[(1 * ROWS + i) * PA_LD + lane] = (uint16_t)(mb >> 16);
+            xt[(2 * ROWS + i) * PA_LD + lane] = (uint16_t)(__float_as_uint(r2) >> 16);
+        }
+        *reinterpret_cast<uint4*>(&tw[lane * 4]) = rw;
         if (b0 == bbeg) STAMP(1);
         if (b0 + 64 < bend) fetch(b0 + 64);           // in flight during the MFMAs below
-        // always the 16 k-steps of a super-tile (sequences past the chunk end carry dz = 0)
-#pragma unroll 4
-        for (int s = 0; s < 16; ++s) {
-            const int col = 4 * s + g;
-            float qv[WGT];
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int j = 0; j < WGT; ++j) qv[j] = tq[(16 * j + c) * QA_LD + col];
-            const float dzb = tdz[col];
-            const uint4 wv = tw[col];
-            // bit of channel r = 16t + c: word t>>1, bit 16(t&1) + c -> shift by c once per word
-            const uint32_t wds[4] = {wv.x >> c, wv.y >> c, wv.z >> c, wv.w >> c};
-            const uint32_t dzbits = __float_as_uint(dzb);
+        for (int kk = 0; kk < 2; ++kk) {               // 32 sequences per MFMA
+            bf16x8 bx[3][WGT];
 #pragma unroll
-            for (int t = 0; t < FC_MT; ++t) {
-                const int m = __builtin_amdgcn_sbfe(wds[t >> 1], 16 * (t & 1), 1);      // 0 or -1
-                const float e = __uint_as_float(dzbits & (uint32_t)m);
-                se[t] += e;
+            for (int p3 = 0; p3 < 3; ++p3)
 #pragma unroll
-                for (int j = 0; j < WGT; ++j) acc[t][j] = MFMA16(e, qv[j], acc[t][j]);
+                for (int j = 0; j < WGT; ++j)
+                    bx[p3][j] = *reinterpret_cast<const bf16x8*>(&xt[(p3 * ROWS + 16 * j + c) * PA_LD + 32 * kk + 8 * g]);
+#pragma unroll
+            for (int tp = 0; tp < (FC_MT + 1) / 2; ++tp) {
+                // channels 32tp .. 32tp+31 live in word tp of every sequence: eight sequences' words
+                uint32_t wd[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) wd[i] = tw[(32 * kk + 8 * g + i) * 4 + tp];
+#pragma unroll
+                for (int th = 0; th < 2; ++th) {
+                    const int t = 2 * tp + th;
+                    if (t >= FC_MT) break;
+                    // A[row r = 16t + c][k = sequence 8g + i]: bit 16th + c of word i -> bf16 1.0 / 0.0
+                    u32x4 av;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int m0 = __builtin_amdgcn_sbfe(wd[2 * i] >> c, 16 * th, 1);       // 0 / -1
+                        const int m1 = __builtin_amdgcn_sbfe(wd[2 * i + 1] >> c, 16 * th, 1);
+                        av[i] = ((uint32_t)m0 & 0x00003f80u) | ((uint32_t)m1 & 0x3f800000u);
+                    }
+                    const bf16x8 afr = __builtin_bit_cast(bf16x8, av);
+#pragma unroll
+                    for (int p3 = 0; p3 < 3; ++p3)
+#pragma unroll
+                        for (int j = 0; j < WGT; ++j)
+                            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bx[p3][j], acc[t][j], 0, 0, 0);
+                }
             }
         }
+        __builtin_amdgcn_wave_barrier();
     }
     STAMP(2);
-    // D[r][w]: lane holds column w = w0 + 16j + c, rows r = 16t + 4g + i
+    // D[r][w]: lane holds column w = w0 + 16j + c, rows r = 16t + 4g + i; column n carries Se.
+    // (Staging the tile through LDS for row-contiguous stores was tried: twice as slow as these
+    // direct stores, 16.8 K against 8.5 K cycles per wave.)
 #pragma unroll
     for (int j = 0; j < WGT; ++j) {
         const int w = w0 + 16 * j + c;
-        if (w < NS) {
 #pragma unroll
-            for (int t = 0; t < FC_MT; ++t)
+        for (int t = 0; t < FC_MT; ++t)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = 16 * t + 4 * g + i;
-                    if (r < FC_H) EQp[(((size_t)u * ACH + ch) * FC_H + r) * NS + w] = acc[t][j][i];
+            for (int i = 0; i < 4; ++i) {
+                const int r = 16 * t + 4 * g + i;
+                if (r < FC_H) {
+                    if (w == n) Sep[((size_t)u * ACH + ch) * FC_H + r] = acc[t][j][i];
+                    else if (w < NS) EQp[(((size_t)u * ACH + ch) * FC_H + r) * NS + w] = acc[t][j][i];
                 }
-        }
-    }
-    if (grp == 0) {
-        // se[t] of lane (g, c) = sum over the sequences 4s+g of e[.][16t + c]: add the four groups
-#pragma unroll
-        for (int t = 0; t < FC_MT; ++t) {
-            float sv = se[t];
-            sv += __shfl_xor(sv, 16, 64);
-            sv += __shfl_xor(sv, 32, 64);
-            const int r = 16 * t + c;
-            if (g == 0 && r < FC_H) Sep[((size_t)u * ACH + ch) * FC_H + r] = sv;
-        }
+            }
     }
     STAMP(3);
 }
 
 int launch_passA(explainn_ctx* c, int B, hipStream_t s) {
 #define CALL(N)                                                                                  \
-    hipLaunchKernelGGL(passA_kernel<N>, dim3(c->ACH, c->U, fc_ng(N)), dim3(64), 0, s,            \
+    hipLaunchKernelGGL(passA_kernel<N>, dim3(c->ACH, c->U, pa_ng(N)), dim3(64), 0, s,            \
                        c->ext, c->alpha, c->shift, c->dz, c->bits, c->EQp, c->Sep, c->n, c->Bs,  \
                        B, c->ACH)
     NQ_DISPATCH(c->NQ, CALL);
@@ -393,10 +431,10 @@ __global__ __launch_bounds__(256) void passB_kernel(
     const double* __restrict__ mug, const double* __restrict__ sig1, float* __restrict__ dy,
     float* __restrict__ S12p, int n, int Bs, int B, int U, int xcd_map, int nx) {
     constexpr int NS = ns_stride(NQ), NW16 = fc_nw16(NQ), WGT = fc_wgt(NQ), NG = fc_ng(NQ);
-    constexpr int RK4 = FC_H / 4, MK = 4 * NW16;       // k-steps of the T.e and of the M.q product
+    constexpr int TBW = 3 * 4 * 256, MK = 4 * NW16;    // floats of one w tile's T pieces; k-steps of M.q
     extern __shared__ __attribute__((aligned(16))) float smemB[];
-    float* Tf = smemB;                                 // [WGT][RK4][64]
-    float* Mf = Tf + WGT * RK4 * 64;                   // [WGT][MK][64]
+    float* Tf = smemB;                                 // [WGT][3 pieces][4 k-steps][64 lanes][8 bf16]
+    float* Mf = Tf + WGT * TBW;                        // [WGT][MK][64]
     float* k0s = Mf + WGT * MK * 64;                   // [WGT*16]
     const int grp = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int u, bx;
@@ -406,14 +444,13 @@ __global__ __launch_bounds__(256) void passB_kernel(
     const int j0 = grp * WGT;                          // first w tile of this group
     const int ntile = min(WGT, NW16 - j0);             // w tiles this group really has
     STAMP(0);
-    // A fragments Tf[(j*RK4+s)*64+l] = T[r=4s+(l>>4)][w=16(j0+j)+(l&15)], Mf[(j*MK+kq)*64+l] =
-    // M[v=16(kq>>2)+4(l>>4)+(kq&3)][w=16(j0+j)+(l&15)] are laid out by the mid kernels; copy them
-    // with float4, all loads before the stores
+    // A fragments: T as bf16 pieces (Tf) and Mf[(j*MK+kq)*64+l] = M[v=16(kq>>2)+4(l>>4)+(kq&3)][w=16(j0+j)+(l&15)]
+    // are laid out by the mid kernels; copy them with float4, all loads before the stores
     {
-        constexpr int NT4 = WGT * RK4 * 16, NM4 = WGT * MK * 16, N4 = NT4 + NM4;
-        const float4* srcT = reinterpret_cast<const float4*>(Ttf + ((size_t)u * NW16 + j0) * RK4 * 64);
+        constexpr int NT4 = WGT * TBW / 4, NM4 = WGT * MK * 16, N4 = NT4 + NM4;
+        const float4* srcT = reinterpret_cast<const float4*>(Ttf + ((size_t)u * NW16 + j0) * TBW);
         const float4* srcM = reinterpret_cast<const float4*>(Mff + ((size_t)u * NW16 + j0) * MK * 64);
-        const int lim_t = ntile * RK4 * 16, lim_m = ntile * MK * 16;
+        const int lim_t = ntile * TBW / 4, lim_m = ntile * MK * 16;
         float4* dst = reinterpret_cast<float4*>(Tf);  // Mf follows Tf contiguously
         float4 tv[(N4 + 255) / 256];
 #pragma unroll
@@ -453,15 +490,40 @@ __global__ __launch_bounds__(256) void passB_kernel(
         const float dzb = dz[(size_t)u * Bs + bc];
 #pragma unroll
         for (int kq = 0; kq < MK; ++kq) KEEP(exr[kq]);
-        // channel r = 4s + g: word (4s)>>5, bit (4s & 31) + g -> shift by g once per word
-        const uint32_t wds[4] = {wv.x >> g, wv.y >> g, wv.z >> g, wv.w >> g};
-        const uint32_t dzbits = __float_as_uint(dzb);
         float nq[MK];
 #pragma unroll
         for (int kq = 0; kq < MK; ++kq)
             nq[kq] = (16 * (kq >> 2) + 4 * g + (kq & 3) < n) ? -qval(a1, exr[kq], s1) : 0.f;
         float sA = 0.f, sB = 0.f;
         if (it == 0) STAMP_AFTER_LOADS(2);
+        // P[w][b] = sum_r T[r][w] bit[b][r] on the bf16 matrix core: the bits are exact in bf16 and T
+        // is the exact sum of its three bf16 pieces, so every product is exact and the sum is an fp32
+        // accumulation -- at 3/16 of the fp32-MFMA cost (25 k-steps of 16x16x4 became 4 x 3 of
+        // 16x16x32).  B operand: element i of lane (g, c) = bit of channel 32kk + 8g + i of sequence c.
+        f32x4 accP[WGT];
+#pragma unroll
+        for (int j = 0; j < WGT; ++j) accP[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const uint32_t wsv[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const uint32_t wg = wsv[kk] >> (8 * g);
+            u32x4 bv;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m0 = __builtin_amdgcn_sbfe(wg, 2 * i, 1), m1 = __builtin_amdgcn_sbfe(wg, 2 * i + 1, 1);
+                bv[i] = ((uint32_t)m0 & 0x00003f80u) | ((uint32_t)m1 & 0x3f800000u);
+            }
+            const bf16x8 bfr = __builtin_bit_cast(bf16x8, bv);
+#pragma unroll
+            for (int j = 0; j < WGT; ++j)
+#pragma unroll
+                for (int p3 = 0; p3 < 3; ++p3) {
+                    const bf16x8 afr = *reinterpret_cast<const bf16x8*>(
+                        reinterpret_cast<const uint16_t*>(Tf) + (((j * 3 + p3) * 4 + kk) * 64 + lane) * 8);
+                    accP[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr, accP[j], 0, 0, 0);
+                }
+        }
+        // - sum_v M[v][w] q[b][v] - k0'[w] stays on the exact-fp32 MFMA (both operands are real-valued)
         f32x4 acc[WGT];
 #pragma unroll
         for (int j = 0; j < WGT; ++j) {
@@ -469,16 +531,13 @@ __global__ __launch_bounds__(256) void passB_kernel(
             acc[j][0] = -v.x; acc[j][1] = -v.y; acc[j][2] = -v.z; acc[j][3] = -v.w;
         }
 #pragma unroll
-        for (int s = 0; s < RK4; ++s) {
-            const int m = __builtin_amdgcn_sbfe(wds[s >> 3], 4 * (s & 7), 1);           // 0 or -1
-            const float e = __uint_as_float(dzbits & (uint32_t)m);
-#pragma unroll
-            for (int j = 0; j < WGT; ++j) acc[j] = MFMA16(Tf[(j * RK4 + s) * 64 + lane], e, acc[j]);
-        }
-#pragma unroll
         for (int kq = 0; kq < MK; ++kq)
 #pragma unroll
             for (int j = 0; j < WGT; ++j) acc[j] = MFMA16(Mf[(j * MK + kq) * 64 + lane], nq[kq], acc[j]);
+#pragma unroll
+        for (int j = 0; j < WGT; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][i] = fmaf(dzb, accP[j][i], acc[j][i]);      // e = dz * bit
         if (it == 0) STAMP(3);
         // D[w][b]: lane holds its sequence b, rows w = 16(j0+j) + 4g + i = the v of register 4(j0+j)+i
 #pragma unroll
@@ -515,7 +574,7 @@ __global__ __launch_bounds__(256) void passB_kernel(
 template <int NQ>
 static size_t passB_lds() {
     constexpr int WGT = fc_wgt(NQ), MK = 4 * fc_nw16(NQ);
-    return (size_t)(WGT * (FC_H / 4) * 64 + WGT * MK * 64 + WGT * 16) * sizeof(float);
+    return (size_t)(WGT * 3 * 4 * 256 + WGT * MK * 64 + WGT * 16) * sizeof(float);
 }
 
 int launch_passB(explainn_ctx* c, int B, hipStream_t s) {

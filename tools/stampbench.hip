@@ -45,7 +45,7 @@ int main() {
     CK(hipMemcpy(A2f, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
     uint4* bits = (uint4*)dalloc((size_t)U * Bs * 16 + 64); float* z = (float*)dalloc((size_t)U * Bs * 4); float* o = (float*)dalloc((size_t)U * Bs * 4);
     float* dz = (float*)dalloc((size_t)U * Bs * 4 + 64); float* EQp = (float*)dalloc((size_t)U * ACH * 100 * NS * 4); float* Sep = (float*)dalloc((size_t)U * ACH * 100 * 4);
-    float* Tt = (float*)dalloc((size_t)(U * 100 + 2) * NS * 8); float* M = (float*)dalloc((size_t)(U * NS + 2) * NS * 8); float* k0p = (float*)dalloc(U * NS * 4);
+    float* Tt = (float*)dalloc((size_t)U * NW16 * 3072 * 4 + (size_t)(U * 100 + 2) * NS * 8); float* M = (float*)dalloc((size_t)(U * NS + 2) * NS * 8); float* k0p = (float*)dalloc(U * NS * 4);
     double* mug = (double*)dalloc(U * 8); double* sig1 = (double*)dalloc(U * 8); std::vector<double> one(U, 1.0); CK(hipMemcpy(sig1, one.data(), U * 8, hipMemcpyHostToDevice));
     float* dy = (float*)dalloc((size_t)U * n * Bs * 4); float* S12p = (float*)dalloc((size_t)U * (Bs / 16) * 2 * 4);
     float* fz = (float*)dalloc(U * 4);
