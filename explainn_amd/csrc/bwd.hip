@@ -49,12 +49,16 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
         const size_t ch = (size_t)u * FC_H + r;
         V1s[r * ld + w] = fc1_w[ch * n + w];
         A2s[r * ld + w] = A2[ch * NS + w];
+    }
+    // passA's partial sums are stored w-major (EQp[..][w][r]): r is the fast index here
+    for (int e = tid; e < FC_H * n; e += 1024) {
+        const int w = e / FC_H, r = e % FC_H;
         double eq = 0;
         for (int c0 = 0; c0 < ACH; c0 += 8) {         // eight partials in flight, fixed-order sum
             float pv[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                pv[i] = EQp[(((size_t)u * ACH + min(c0 + i, ACH - 1)) * FC_H + r) * NS + w];
+                pv[i] = EQp[(((size_t)u * ACH + min(c0 + i, ACH - 1)) * NS + w) * FC_H + r];
 #pragma unroll
             for (int i = 0; i < 8; ++i) KEEP(pv[i]);
 #pragma unroll
@@ -219,12 +223,17 @@ __global__ __launch_bounds__(1024) void mid_big_kernel(
         const size_t ch = (size_t)u * FC_H + r;
         V1s[r * ld + w] = fc1_w[ch * n + w];
         A2s[r * ld + w] = A2[ch * NS + w];
+    }
+    // passA's partial sums are stored w-major (EQp[..][w][r]): r is the fast index here
+    for (int e = tid; e < FC_H * n; e += NT) {
+        const int w = e / FC_H, r = e % FC_H;
+        const size_t ch = (size_t)u * FC_H + r;
         double eq = 0;
         for (int c0 = 0; c0 < ACH; c0 += 8) {         // eight partials in flight, fixed-order sum
             float pv[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                pv[i] = EQp[(((size_t)u * ACH + min(c0 + i, ACH - 1)) * FC_H + r) * NS + w];
+                pv[i] = EQp[(((size_t)u * ACH + min(c0 + i, ACH - 1)) * NS + w) * FC_H + r];
 #pragma unroll
             for (int i = 0; i < 8; ++i) KEEP(pv[i]);
 #pragma unroll

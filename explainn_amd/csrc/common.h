@@ -71,7 +71,7 @@ struct explainn_ctx {
     float* sig3;          // [U]
     uint4* bits;          // [U][Bs]          100 bits per (unit, sequence): relu'>0 and kept
     float* dz;            // [U][Bs]
-    float* EQp;           // [U][ACH][100][NS]
+    float* EQp;           // [U][ACH][NS][100]  passA's partial sums, w-major (four rows r = one 16-byte store)
     float* Sep;           // [U][ACH][100]
     float* EQs;           // [U][100][NS]
     float* Tt;            // [U][100][NS]

@@ -386,22 +386,23 @@ __global__ __launch_bounds__(64) void passA_kernel(const float* __restrict__ ext
         __builtin_amdgcn_wave_barrier();
     }
     STAMP(2);
-    // D[r][w]: lane holds column w = w0 + 16j + c, rows r = 16t + 4g + i; column n carries Se.
-    // (Staging the tile through LDS for row-contiguous stores was tried: twice as slow as these
-    // direct stores, 16.8 K against 8.5 K cycles per wave.)
+    // D[r][w]: lane holds column w = w0 + 16j + c, rows r = 16t + 4g + i (i = 0..3 consecutive);
+    // column n carries Se.  The partial sums are stored w-major, EQp[..][w][r], so that a lane's four
+    // rows are one 16-byte store (r-major they were 56 four-byte stores per lane, each instruction
+    // touching four rows: a quarter of the wave's life.  Staging the tile through LDS instead was
+    // tried and was twice as slow).
 #pragma unroll
     for (int j = 0; j < WGT; ++j) {
         const int w = w0 + 16 * j + c;
 #pragma unroll
-        for (int t = 0; t < FC_MT; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = 16 * t + 4 * g + i;
-                if (r < FC_H) {
-                    if (w == n) Sep[((size_t)u * ACH + ch) * FC_H + r] = acc[t][j][i];
-                    else if (w < NS) EQp[(((size_t)u * ACH + ch) * FC_H + r) * NS + w] = acc[t][j][i];
-                }
+        for (int t = 0; t < FC_MT; ++t) {
+            const int r = 16 * t + 4 * g;
+            if (r < FC_H) {                            // FC_H is a multiple of 4: all four rows or none
+                const float4 v = make_float4(acc[t][j][0], acc[t][j][1], acc[t][j][2], acc[t][j][3]);
+                if (w == n) *reinterpret_cast<float4*>(&Sep[((size_t)u * ACH + ch) * FC_H + r]) = v;
+                else if (w < NS) *reinterpret_cast<float4*>(&EQp[(((size_t)u * ACH + ch) * NS + w) * FC_H + r]) = v;
             }
+        }
     }
     STAMP(3);
 }
