@@ -164,7 +164,11 @@ def kernel_model(w, B):
     n = Lo // 7
     nt = (K + 1) // 2
     return {
-        # exact-fp32 MFMA FLOPs on the UNPADDED problem (100 hidden channels, n pooled positions)
+        # FLOPs of the UNPADDED problem (100 hidden channels, n pooled positions), priced against
+        # the fp32 MFMA peak.  fc_fwd runs on the exact-fp32 MFMA; passA and the T.bit part of passB
+        # have a bit matrix as one operand and run on the bf16 MFMA with the real operand split
+        # exactly into three bf16 pieces (fp32-equivalent result, 3/16 of the fp32 cost), so their
+        # fraction of the fp32 peak may exceed what an fp32-MFMA kernel could reach
         "fc_fwd": ("mfma_f32", 2.0 * 100 * n * B * U),
         "passA": ("mfma_f32", 2.0 * 100 * n * B * U),
         "passB": ("mfma_f32", 2.0 * (100 + n) * n * B * U),

@@ -42,6 +42,10 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
     float* md2s = se + FC_H;                 // [100]
     float* cfs = md2s + FC_H;                // [100]  md2h / sig2
     float* md2hs = cfs + FC_H;               // [100]
+    float* VCl = md2hs + FC_H;               // [100][ld]  (V1.C), read once here: the dV1 loop below
+    float* svl = VCl + FC_H * ld;            // [100]      then runs on LDS alone (its five global
+    float* gsl = svl + FC_H;                 // [100]      loads per element made it a latency chain:
+    float* sgl = gsl + FC_H;                 // [100]      12 K of the block's 31 K cycles)
     const int u = blockIdx.x, tid = threadIdx.x;
     STAMP(0);
     for (int e = tid; e < FC_H * n; e += 1024) {
@@ -49,6 +53,7 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
         const size_t ch = (size_t)u * FC_H + r;
         V1s[r * ld + w] = fc1_w[ch * n + w];
         A2s[r * ld + w] = A2[ch * NS + w];
+        VCl[r * ld + w] = VC[ch * NS + w];
     }
     // passA's partial sums are stored w-major (EQp[..][w][r]): r is the fast index here
     for (int e = tid; e < FC_H * n; e += 1024) {
@@ -66,7 +71,8 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
         }
         EQl[r * ld + w] = (float)eq;
     }
-    for (int w = tid; w < n; w += 1024) qb[w] = (float)qbar[(size_t)u * NS + w];
+    double* qbd = reinterpret_cast<double*>((reinterpret_cast<size_t>(sgl + FC_H) + 7) & ~size_t(7));   // [n] doubles
+    for (int w = tid; w < n; w += 1024) { const double v = qbar[(size_t)u * NS + w]; qb[w] = (float)v; qbd[w] = v; }
     for (int r = tid; r < FC_H; r += 1024) {
         double s = 0;
         for (int c = 0; c < ACH; ++c) s += (double)Sep[((size_t)u * ACH + c) * FC_H + r];
@@ -83,7 +89,7 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
         for (int w = 0; w < n; ++w) {
             const double eq = (double)EQl[r * ld + w];
             sAE = fma((double)A2s[r * ld + w], eq, sAE);
-            sVE = fma((double)V1s[r * ld + w], eq - ser * qbar[(size_t)u * NS + w], sVE);
+            sVE = fma((double)V1s[r * ld + w], eq - ser * qbd[w], sVE);
         }
         const double v2 = (double)fc2_w[ch], sg = (double)sig2[ch];
         g_fc2_w[ch] = (float)(sc * (sAE + (double)sh2[ch] * ser));
@@ -94,6 +100,7 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
         md2s[r] = (float)(db2 / (double)B);
         md2hs[r] = (float)(dg2 / (double)B);
         cfs[r] = (float)((dg2 / (double)B) / sg);
+        svl[r] = (float)v2; gsl[r] = g2[ch]; sgl[r] = (float)sg;
     }
     __syncthreads();
     STAMP(2);
@@ -152,16 +159,16 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
         if (e < 0) break;                              // tile waves skip
         const int r = e / NS, w = e % NS;
         const size_t ch = (size_t)u * FC_H + r;
-        const double sv = sc * (double)fc2_w[ch];
+        const double sv = sc * (double)svl[r];
         float tv = 0.f;
         if (w < n) {
             tv = (float)(sv * (double)A2s[r * ld + w]);
-            double hq = (double)VC[ch * NS + w];       // (V1.C)[r][w], computed once by prep2
-            const double sg = (double)sig2[ch];
+            double hq = (double)VCl[r * ld + w];       // (V1.C)[r][w], computed once by prep2
+            const double sg = (double)sgl[r];
             hq *= (double)B / sg;
-            const double val = ((double)g2[ch] / sg) *
+            const double val = ((double)gsl[r] / sg) *
                                (sv * (double)EQl[r * ld + w] -
-                                (double)md2s[r] * (double)B * qbar[(size_t)u * NS + w] -
+                                (double)md2s[r] * (double)B * qbd[w] -
                                 (double)md2hs[r] * hq);
             g_fc1_w[ch * n + w] = (float)val;
         }
@@ -186,7 +193,7 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
         double k0 = 0;
         if (w < n) {
             for (int r = 0; r < FC_H; ++r) k0 = fma((double)A2s[r * ld + w], (double)md2s[r], k0);
-            for (int v = 0; v < n; ++v) k0 -= qbar[(size_t)u * NS + v] * (double)Ms[v * n + w];
+            for (int v = 0; v < n; ++v) k0 -= qbd[v] * (double)Ms[v * n + w];
         }
         k0p[(size_t)u * NS + w] = (float)k0;
     }
@@ -361,7 +368,7 @@ static size_t mid_big_lds(int n) {
 }
 
 static size_t mid_fused_lds(int n) {
-    return ((size_t)3 * FC_H * (n + 1) + (size_t)n * n + n + 4 * FC_H) * sizeof(float);
+    return ((size_t)4 * FC_H * (n + 1) + (size_t)n * n + n + 7 * FC_H + 2) * sizeof(float) + (size_t)n * sizeof(double);
 }
 
 int launch_mid_bwd(explainn_ctx* c, const explainn_params* p, const explainn_grads* g, int B,

@@ -53,7 +53,7 @@ struct explainn_ctx {
     double* sig1;         // [U4]
     double* Gw;           // [U4][4k]
     float* Wt;            // [Uq][k][5][4]    filter taps, unit-quad interleaved, code 4 -> 0
-    float* lut;           // [U4/2][ceil(k/2)][16] float2: dinucleotide tables per unit pair
+    float* lut;           // [U4/4][ceil(k/2)][16] float4: dinucleotide tables per unit quad
     float* ext;           // [U4][n][Bs]      pooled extreme of the raw gather sum
     uint8_t* idx;         // [U4][n][Bs]      argmax offset 0..6 inside the pooling window
     float* qs0;           // [U][NS]          shift for the q moments (q of sequence 0)
@@ -254,7 +254,7 @@ __device__ __forceinline__ void filter_tables_unit(const float* __restrict__ con
     }
     for (int j = tid; j < k; j += nthreads) Wt[((size_t)(u >> 2) * k + j) * 20 + 16 + (u & 3)] = 0.f;
     __syncthreads();
-    // lut[pair][t][c0 c1].{x,y} = W[u][c0][2t] + W[u][c1][2t+1]
+    // lut[quad][t][c0 c1].{x,y,z,w} = W[u][c0][2t] + W[u][c1][2t+1] for the four units of the quad
     const int NT = (k + 1) / 2;
     for (int e = tid; e < NT * 16; e += nthreads) {
         const int t = e >> 4, code4 = e & 15;
@@ -263,7 +263,7 @@ __device__ __forceinline__ void filter_tables_unit(const float* __restrict__ con
             const int j = 2 * t + i;
             if (j < k) sum += wsh[((code4 >> (2 * i)) & 3) * k + j];
         }
-        lut[(((size_t)(u >> 1) * NT + t) * 16 + code4) * 2 + (u & 1)] = sum;
+        lut[(((size_t)(u >> 2) * NT + t) * 16 + code4) * 4 + (u & 3)] = sum;
     }
 }
 

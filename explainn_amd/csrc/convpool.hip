@@ -21,7 +21,8 @@
 // The tables LUT[pair][t][code4] = (W[u0][c0][2t] + W[u0][c1][2t+1], same for u1),
 // c_i = (code4 >> 2i) & 3, are written by prep1 (prep.hip) from the current filters.
 
-// byte offset (x8) of the 2-mer starting x bases into the window; x is compile-time after unrolling
+// byte offset (x ESZ) of the 2-mer starting x bases into the window; x is compile-time after unrolling
+template <int ESZ>
 __device__ __forceinline__ uint32_t dimer_off(uint32_t w0, uint32_t w1, uint32_t w2, int x) {
     const int bit = 2 * x;
     uint32_t v;
@@ -30,20 +31,30 @@ __device__ __forceinline__ uint32_t dimer_off(uint32_t w0, uint32_t w1, uint32_t
     else if (bit >= 64) v = w2 >> (bit - 64);
     else if (bit < 32) v = __funnelshift_r(w0, w1, bit);
     else v = __funnelshift_r(w1, w2, bit - 32);
-    return (v & 0xfu) * 8u;
+    return (v & 0xfu) * (uint32_t)ESZ;
 }
 
-// The gather + pooling of one wavefront: lane = sequence b, two units (one `pair`), pooling windows
-// [wbeg, wend).  `sink(w, ext0, i0, ext1, i1)` receives the pooled extreme (raw gather sum) and its
-// offset inside the window for both units.  L2/Wp: the pair's dinucleotide and per-tap tables in
-// LDS; pks/nms: this wave's private code tiles ([PWC][64] / [NWC][64] words).
-template <int K, typename Sink>
-__device__ __forceinline__ void conv_pool_windows(const float2* L2, const float2* Wp, uint32_t* pks,
+// The gather + pooling of one wavefront: lane = sequence b, NU units (2 or 4), pooling windows
+// [wbeg, wend).  `sink(w, ext, off)` receives the pooled extremes (raw gather sums, NU of them) and
+// their offsets inside the window.  L2/Wp: the units' dinucleotide and per-tap tables in LDS (entries
+// of NU floats); pks/nms: this wave's private code tiles ([PWC][64] / [NWC][64] words).
+// NU = 4 (the training / default eval filter bank): one ds_read_b128 per (position, tap pair) feeds
+// four units, and the 2-mer offsets, the window bookkeeping and the N corrections are shared by four
+// units instead of two -- conv_pool is instruction-issue-bound (profiles/r02: 255 VALU + 47 LDS
+// instructions per window and unit pair), so instructions per unit are what counts.
+template <int NU> struct fvec;
+template <> struct fvec<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct fvec<4> { typedef float type __attribute__((ext_vector_type(4))); };
+
+template <int K, int NU, typename Sink>
+__device__ __forceinline__ void conv_pool_windows(const void* L2, const void* Wp, uint32_t* pks,
                                                   uint32_t* nms, const uint32_t* __restrict__ pk2,
-                                                  const uint32_t* __restrict__ nmask, float sg0,
-                                                  float sg1, int b, int lane, int wbeg, int wend,
-                                                  int Bs, int PW, int NW, Sink sink,
+                                                  const uint32_t* __restrict__ nmask,
+                                                  const float (&sg)[NU], int b, int lane, int wbeg,
+                                                  int wend, int Bs, int PW, int NW, Sink sink,
                                                   bool staged = false) {
+    typedef typename fvec<NU>::type fv;
+    constexpr int ESZ = NU * 4;                 // bytes per table entry
     constexpr int NT = (K + 1) / 2;             // 2-mer tables
     constexpr int NX = POOLW + 2 * (NT - 1);    // distinct 2-mer start offsets inside a window
     constexpr int SPAN = POOLW + K - 1;         // positions a pooling window reads
@@ -79,20 +90,18 @@ __device__ __forceinline__ void conv_pool_windows(const float2* L2, const float2
         }
         constexpr uint32_t HIMASK = SPAN > 32 ? ((SPAN >= 64) ? 0xffffffffu : ((1u << (SPAN - 32)) - 1u)) : 0u;
         constexpr uint32_t LOMASK = SPAN >= 32 ? 0xffffffffu : ((1u << SPAN) - 1u);
-        float2 acc[POOLW];
+        fv acc[POOLW];
 #pragma unroll
-        for (int i = 0; i < POOLW; ++i) acc[i] = make_float2(0.f, 0.f);
+        for (int i = 0; i < POOLW; ++i) acc[i] = fv(0.f);
         {
             uint32_t a8[NX];
 #pragma unroll
-            for (int x = 0; x < NX; ++x) a8[x] = dimer_off(w0, w1, w2, x);
+            for (int x = 0; x < NX; ++x) a8[x] = dimer_off<ESZ>(w0, w1, w2, x);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
 #pragma unroll
-                for (int i = 0; i < POOLW; ++i) {
-                    const float2 v = *reinterpret_cast<const float2*>(Lb + t * 128 + a8[i + 2 * t]);
-                    acc[i].x += v.x; acc[i].y += v.y;
-                }
+                for (int i = 0; i < POOLW; ++i)
+                    acc[i] += *reinterpret_cast<const fv*>(Lb + t * 16 * ESZ + a8[i + 2 * t]);
             }
         }
         // N bases are packed as 'C': take the C tap back out wherever the mask says N.  Per lane and
@@ -107,22 +116,25 @@ __device__ __forceinline__ void conv_pool_windows(const float2* L2, const float2
 #pragma unroll
                 for (int i = 0; i < POOLW; ++i) {
                     const int j = x - i;                 // base x of the window is tap j of position i
-                    if (j >= 0 && j < K) {
-                        const float2 v = *reinterpret_cast<const float2*>(Wb + j * 40 + 8);   // code 1 = C
-                        acc[i].x -= v.x; acc[i].y -= v.y;
-                    }
+                    if (j >= 0 && j < K)
+                        acc[i] -= *reinterpret_cast<const fv*>(Wb + j * 5 * ESZ + ESZ);   // code 1 = C
                 }
             }
         }
-        float best0 = sg0 * acc[0].x, best1 = sg1 * acc[0].y;
-        int bi0 = 0, bi1 = 0;
+        float ex[NU];
+        int bi[NU];
 #pragma unroll
-        for (int i = 1; i < POOLW; ++i) {
-            const float v0 = sg0 * acc[i].x, v1 = sg1 * acc[i].y;
-            if (v0 > best0) { best0 = v0; bi0 = i; }           // strict: first index wins ties
-            if (v1 > best1) { best1 = v1; bi1 = i; }
+        for (int uu = 0; uu < NU; ++uu) {
+            float best = sg[uu] * acc[0][uu];
+            int bidx = 0;
+#pragma unroll
+            for (int i = 1; i < POOLW; ++i) {
+                const float v = sg[uu] * acc[i][uu];
+                if (v > best) { best = v; bidx = i; }          // strict: first index wins ties
+            }
+            ex[uu] = sg[uu] * best; bi[uu] = bidx;
         }
-        sink(w, sg0 * best0, bi0, sg1 * best1, bi1);
+        sink(w, ex, bi);
     }
     }
 }
@@ -130,7 +142,7 @@ __device__ __forceinline__ void conv_pool_windows(const float2* L2, const float2
 template <int K>
 __global__ __launch_bounds__(64) void conv_pool_kernel(const uint32_t* __restrict__ pk2,
                                                        const uint32_t* __restrict__ nmask,
-                                                       const float2* __restrict__ lut,
+                                                       const float4* __restrict__ lut,
                                                        const float* __restrict__ Wt,
                                                        const float* __restrict__ gamma1, int U,
                                                        float* __restrict__ ext,
@@ -138,39 +150,35 @@ __global__ __launch_bounds__(64) void conv_pool_kernel(const uint32_t* __restric
                                                        int PW, int NW, int wsplit) {
     constexpr int NT = (K + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) uint32_t csm[];
-    float2* L2 = reinterpret_cast<float2*>(csm);            // [NT][16]
-    float2* Wp = L2 + NT * 16;                              // [K][5]   per-tap table (N path)
+    float4* L2 = reinterpret_cast<float4*>(csm);            // [NT][16]  2-mer sums of the unit quad
+    float4* Wp = L2 + NT * 16;                              // [K][5]    per-tap table (N path)
     // the packed codes are staged per chunk of CPW pooling windows: ~7 KB of LDS per wave at any
     // sequence length (the whole of a 1000-bp sequence was 26 KB and cost two thirds of the occupancy)
     constexpr int CPW = 32;
     constexpr int PWC = ((POOLW * CPW + K + 15) >> 4) + 3;
     uint32_t* pks = reinterpret_cast<uint32_t*>(Wp + K * 5); // [PWC][64]
     uint32_t* nms = pks + (size_t)PWC * 64;                  // [NWC][64]
-    const int pair = blockIdx.y, lane = threadIdx.x;
+    const int quad = blockIdx.y, lane = threadIdx.x;
     const int b = (blockIdx.x / wsplit) * 64 + lane;
-    // the pooling windows of a (tile, pair) are split over `wsplit` wavefronts: more waves per
+    // the pooling windows of a (tile, quad) are split over `wsplit` wavefronts: more waves per
     // SIMD to hide the LDS latency (a wave issues at most one instruction per 4 cycles)
     const int wper = (n + wsplit - 1) / wsplit;
     const int wbeg = (blockIdx.x % wsplit) * wper, wend = min(n, wbeg + wper);
-    const int quad = pair >> 1, off = (pair & 1) * 2;
     STAMP(0);
     {
         // both tables with all their loads in flight before the first LDS store
-        const float2* src = lut + (size_t)pair * NT * 16;
+        const float4* src = lut + (size_t)quad * NT * 16;
+        const float4* wsrc = reinterpret_cast<const float4*>(Wt) + (size_t)quad * K * 5;
         constexpr int NL = (NT * 16 + 63) / 64, NWP = (K * 5 + 63) / 64;
-        float2 lv[NL], wv[NWP];
+        float4 lv[NL], wv[NWP];
 #pragma unroll
         for (int j = 0; j < NL; ++j) lv[j] = src[min(lane + 64 * j, NT * 16 - 1)];
 #pragma unroll
-        for (int j = 0; j < NWP; ++j) {
-            const int i = min(lane + 64 * j, K * 5 - 1);
-            const float* w = Wt + ((size_t)quad * K + i / 5) * 20 + (i % 5) * 4 + off;
-            wv[j] = make_float2(w[0], w[1]);
-        }
+        for (int j = 0; j < NWP; ++j) wv[j] = wsrc[min(lane + 64 * j, K * 5 - 1)];
 #pragma unroll
-        for (int j = 0; j < NL; ++j) { KEEP(lv[j].x); KEEP(lv[j].y); }
+        for (int j = 0; j < NL; ++j) { KEEP(lv[j].x); KEEP(lv[j].y); KEEP(lv[j].z); KEEP(lv[j].w); }
 #pragma unroll
-        for (int j = 0; j < NWP; ++j) { KEEP(wv[j].x); KEEP(wv[j].y); }
+        for (int j = 0; j < NWP; ++j) { KEEP(wv[j].x); KEEP(wv[j].y); KEEP(wv[j].z); KEEP(wv[j].w); }
 #pragma unroll
         for (int j = 0; j < NL; ++j)
             if (lane + 64 * j < NT * 16) L2[lane + 64 * j] = lv[j];
@@ -178,18 +186,20 @@ __global__ __launch_bounds__(64) void conv_pool_kernel(const uint32_t* __restric
         for (int j = 0; j < NWP; ++j)
             if (lane + 64 * j < K * 5) Wp[lane + 64 * j] = wv[j];
     }
-    // sign(alpha) = sign(gamma1): the pooling direction does not need the BatchNorm statistics,
-    // so this kernel can run beside the input-moment chain
-    const float sg0 = (pair * 2 < U && gamma1[pair * 2] < 0.f) ? -1.f : 1.f;
-    const float sg1 = (pair * 2 + 1 < U && gamma1[pair * 2 + 1] < 0.f) ? -1.f : 1.f;
+    // sign(alpha) = sign(gamma1): the pooling direction does not need the BatchNorm statistics
+    float sg[4];
+#pragma unroll
+    for (int uu = 0; uu < 4; ++uu) sg[uu] = (quad * 4 + uu < U && gamma1[quad * 4 + uu] < 0.f) ? -1.f : 1.f;
     __syncthreads();
     STAMP(1);
-    conv_pool_windows<K>(L2, Wp, pks, nms, pk2, nmask, sg0, sg1, b, lane, wbeg, wend, Bs, PW, NW,
-                         [&](int w, float e0, int i0, float e1, int i1) {
-                             const size_t o0 = ((size_t)(pair * 2) * n + w) * Bs + b, o1 = o0 + (size_t)n * Bs;
-                             ext[o0] = e0; idx[o0] = (uint8_t)i0;
-                             ext[o1] = e1; idx[o1] = (uint8_t)i1;
-                         });
+    conv_pool_windows<K, 4>(L2, Wp, pks, nms, pk2, nmask, sg, b, lane, wbeg, wend, Bs, PW, NW,
+                            [&](int w, const float (&e)[4], const int (&i)[4]) {
+#pragma unroll
+                                for (int uu = 0; uu < 4; ++uu) {
+                                    const size_t o = ((size_t)(quad * 4 + uu) * n + w) * Bs + b;
+                                    ext[o] = e[uu]; idx[o] = (uint8_t)i[uu];
+                                }
+                            });
     STAMP(2);
 }
 
@@ -214,16 +224,18 @@ static size_t conv_pool_lds(const explainn_ctx* c) {
     const int NT = (c->k + 1) / 2;
     // tables + the chunk tiles [PWC + NWC][64] (see the kernel)
     const int pwc = ((POOLW * 32 + c->k + 15) >> 4) + 3, nwc = ((POOLW * 32 + c->k + 31) >> 5) + 2;
-    return (size_t)(NT * 16 + c->k * 5) * sizeof(float2) + (size_t)(pwc + nwc) * 64 * 4;
+    return (size_t)(NT * 16 + c->k * 5) * sizeof(float4) + (size_t)(pwc + nwc) * 64 * 4;
 }
 
 int launch_conv_pool(explainn_ctx* c, const explainn_params* p, int B, hipStream_t s) {
-    const int wsplit = c->n >= 8 ? 2 : 1;
-    const dim3 grid(((B + 63) / 64) * wsplit, c->U4 / 2);
+    // four units per lane: half the waves of the two-unit version per window split -> split the
+    // windows four ways where there are enough of them
+    const int wsplit = c->n >= 16 ? 4 : (c->n >= 8 ? 2 : 1);
+    const dim3 grid(((B + 63) / 64) * wsplit, c->Uq);
     const size_t sm = conv_pool_lds(c);
 #define CALL(KK)                                                                               \
     hipLaunchKernelGGL(conv_pool_kernel<KK>, grid, dim3(64), sm, s, c->pk2, c->nmask,          \
-                       reinterpret_cast<const float2*>(c->lut), c->Wt, p->bn1_w, c->U, c->ext, c->idx, \
+                       reinterpret_cast<const float4*>(c->lut), c->Wt, p->bn1_w, c->U, c->ext, c->idx, \
                        c->n, c->Bs, c->PW, c->NW, wsplit)
     K_DISPATCH(c->k, CALL);
 #undef CALL
@@ -355,8 +367,11 @@ __global__ __launch_bounds__(256) void eval_fused_kernel(
         __syncthreads();                               // previous pair's phase B is done with LDS
         // ---- stage the pair's tables: LUT, per-tap table, FC1 fragments, sh2 / v2 ----
         {
-            const float2* src = lut + (size_t)pair * NT * 16;
-            for (int i = tid; i < NT * 16; i += 256) L2[i] = src[i];
+            const float4* src = reinterpret_cast<const float4*>(lut) + (size_t)(pair >> 1) * NT * 16;
+            for (int i = tid; i < NT * 16; i += 256) {
+                const float4 v = src[i];
+                L2[i] = (pair & 1) ? make_float2(v.z, v.w) : make_float2(v.x, v.y);
+            }
             const int quad = pair >> 1, off = (pair & 1) * 2;
             for (int i = tid; i < K * 5; i += 256) {
                 const float* wq = Wt + ((size_t)quad * K + i / 5) * 20 + (i % 5) * 4 + off;
@@ -374,17 +389,17 @@ __global__ __launch_bounds__(256) void eval_fused_kernel(
                 }
             }
         }
-        const float sg0 = (gamma1[u0] < 0.f) ? -1.f : 1.f;
-        const float sg1 = (u0 + 1 < U && gamma1[u0 + 1] < 0.f) ? -1.f : 1.f;
+        const float sg[2] = {(gamma1[u0] < 0.f) ? -1.f : 1.f,
+                             (u0 + 1 < U && gamma1[u0 + 1] < 0.f) ? -1.f : 1.f};
         const float al0 = alpha[u0], sf0 = shift[u0];
         const float al1 = alpha[min(u0 + 1, U - 1)], sf1 = shift[min(u0 + 1, U - 1)];
         __syncthreads();
         // ---- phase A: gather + pool + exp -> q tile ----
-        conv_pool_windows<K>(L2, Wp, pks, nms, pk2, nmask, sg0, sg1, b, lane, wbeg, wend, Bs, PW, NW,
-                             [&](int w, float e0, int, float e1, int) {
-                                 qs[w * EVAL_QLD + lane] = qval(al0, e0, sf0);
-                                 qs[(qrows + w) * EVAL_QLD + lane] = qval(al1, e1, sf1);
-                             }, one_chunk);
+        conv_pool_windows<K, 2>(L2, Wp, pks, nms, pk2, nmask, sg, b, lane, wbeg, wend, Bs, PW, NW,
+                                [&](int w, const float (&e)[2], const int (&)[2]) {
+                                    qs[w * EVAL_QLD + lane] = qval(al0, e[0], sf0);
+                                    qs[(qrows + w) * EVAL_QLD + lane] = qval(al1, e[1], sf1);
+                                }, one_chunk);
         // rows n .. 4*nk4-1 are the zero padding of the last k-step
         for (int i = tid; i < 2 * (qrows - n) * 64; i += 256) {
             const int uu = i / ((qrows - n) * 64), r = (i / 64) % (qrows - n), l = i & 63;

@@ -37,27 +37,6 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     return x;
 }
 
-#include <cstdlib>
-// experiment knobs (read once per process): EXPLAINN_FC_LDSPAD = extra dynamic LDS bytes requested by
-// fc_fwd / passB (caps the blocks a CU takes), EXPLAINN_FC_XCD = 1 maps the blocks of one unit to
-// one XCD (ids 8 apart share an XCD under round-robin dispatch) so that they share its L2
-static int env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-static int fc_ldspad() { static int v = env_int("EXPLAINN_FC_LDSPAD", 0); return v; }
-static int fc_xcd() { static int v = env_int("EXPLAINN_FC_XCD", 0); return v; }
-
-// (unit, x) of a workgroup: plain (blockIdx.y, blockIdx.x), or -- XCD-aware -- decoded from a linear
-// id so that the nx workgroups of a unit have ids that differ by multiples of 8
-__device__ __forceinline__ void unit_block(int xcd_map, int nx, int U, int& u, int& x) {
-    if (!xcd_map) { u = blockIdx.y; x = blockIdx.x; return; }
-    const int id = blockIdx.x;                 // grid = (nx * U8, 1, z) with U8 = U rounded up to 8
-    const int xcd = id & 7, slot = id >> 3;
-    x = slot % nx;
-    u = (slot / nx) * 8 + xcd;
-}
-
 #define FC_BTW 4                     // 16-sequence tiles per wavefront in fc_fwd
 #define PB_BTW 4                     // ... in passB
 
@@ -70,8 +49,7 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(
     const uint8_t* __restrict__ keep_mask, uint32_t thresh16, float scale, uint32_t seed_lo,
     uint32_t seed_hi, const float* __restrict__ c2, const float* __restrict__ g3,
     const float* __restrict__ b3, const float* __restrict__ rm3, const float* __restrict__ rv3,
-    float* __restrict__ oout, int n, int Bs, int B, int U, const uint32_t* __restrict__ seed_dev,
-    int xcd_map, int nx) {
+    float* __restrict__ oout, int n, int Bs, int B, int U, const uint32_t* __restrict__ seed_dev) {
     constexpr int NK4 = fc_nk4(NQ), NK4Q = fc_nk4q(NQ);
     constexpr bool TRAIN = MODE != 0;
     // a captured step (hipGraph) reads its dropout seed from device memory, so that replays can
@@ -81,10 +59,7 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(
     float4* Af = reinterpret_cast<float4*>(fsm);            // [FC_MT][NK4Q][64] float4 (4 k-steps each)
     float* sh2s = fsm + FC_MT * NK4Q * 64 * 4;               // [112]
     float* v2s = sh2s + FC_MT * 16;                          // [112]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int u, bx;
-    unit_block(xcd_map, nx, U, u, bx);
-    if (u >= U) return;                                // block-uniform (XCD-aware grids pad U to 8)
+    const int u = blockIdx.y, bx = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
     const float* __restrict__ eu = ext + (size_t)u * n * Bs;
     const int bt0 = (bx * 4 + wave) * FC_BTW;
@@ -223,8 +198,7 @@ static size_t fc_fwd_lds() {
 int launch_fc_fwd(explainn_ctx* c, const explainn_params* p, int B, bool train,
                   const uint8_t* keep_mask, float drop_p, uint64_t seed, hipStream_t s) {
     const int tiles = (B + 15) / 16;
-    const int nx = (tiles + 4 * FC_BTW - 1) / (4 * FC_BTW), xm = fc_xcd();
-    const dim3 grid = xm ? dim3(nx * ((c->U + 7) & ~7)) : dim3(nx, c->U);
+    const dim3 grid((tiles + 4 * FC_BTW - 1) / (4 * FC_BTW), c->U);
     int mode = train ? 1 : 0;
     float scale = 1.f;
     uint32_t thresh = 0;
@@ -237,13 +211,13 @@ int launch_fc_fwd(explainn_ctx* c, const explainn_params* p, int B, bool train,
 #define ARGS c->ext, c->alpha, c->shift, c->A2f, c->sh2, p->fc2_w, c->bits, c->z, keep_mask, thresh, \
              scale, (uint32_t)seed, (uint32_t)(seed >> 32), p->fc2_b, p->bn3_w, p->bn3_b,          \
              p->bn3_rm, p->bn3_rv, c->o, c->n, c->Bs, B, c->U,                                   \
-             (c->capturing ? c->seed_dev : (const uint32_t*)nullptr), xm, nx
+             (c->capturing ? c->seed_dev : (const uint32_t*)nullptr)
 #define CALL(N)                                                                                    \
     switch (mode) {                                                                                \
-        case 0: hipLaunchKernelGGL((fc_fwd_kernel<N, 0>), grid, dim3(256), fc_fwd_lds<N>() + fc_ldspad(), s, ARGS); break; \
-        case 1: hipLaunchKernelGGL((fc_fwd_kernel<N, 1>), grid, dim3(256), fc_fwd_lds<N>() + fc_ldspad(), s, ARGS); break; \
-        case 2: hipLaunchKernelGGL((fc_fwd_kernel<N, 2>), grid, dim3(256), fc_fwd_lds<N>() + fc_ldspad(), s, ARGS); break; \
-        default: hipLaunchKernelGGL((fc_fwd_kernel<N, 3>), grid, dim3(256), fc_fwd_lds<N>() + fc_ldspad(), s, ARGS); break; \
+        case 0: hipLaunchKernelGGL((fc_fwd_kernel<N, 0>), grid, dim3(256), fc_fwd_lds<N>(), s, ARGS); break; \
+        case 1: hipLaunchKernelGGL((fc_fwd_kernel<N, 1>), grid, dim3(256), fc_fwd_lds<N>(), s, ARGS); break; \
+        case 2: hipLaunchKernelGGL((fc_fwd_kernel<N, 2>), grid, dim3(256), fc_fwd_lds<N>(), s, ARGS); break; \
+        default: hipLaunchKernelGGL((fc_fwd_kernel<N, 3>), grid, dim3(256), fc_fwd_lds<N>(), s, ARGS); break; \
     }
     NQ_DISPATCH(c->NQ, CALL);
 #undef CALL
@@ -430,17 +404,14 @@ __global__ __launch_bounds__(256) void passB_kernel(
     const float* __restrict__ shift, const float* __restrict__ dz, const uint4* __restrict__ bits,
     const float* __restrict__ Ttf, const float* __restrict__ Mff, const float* __restrict__ k0p,
     const double* __restrict__ mug, const double* __restrict__ sig1, float* __restrict__ dy,
-    float* __restrict__ S12p, int n, int Bs, int B, int U, int xcd_map, int nx) {
+    float* __restrict__ S12p, int n, int Bs, int B) {
     constexpr int NS = ns_stride(NQ), NW16 = fc_nw16(NQ), WGT = fc_wgt(NQ), NG = fc_ng(NQ);
     constexpr int TBW = 3 * 4 * 256, MK = 4 * NW16;    // floats of one w tile's T pieces; k-steps of M.q
     extern __shared__ __attribute__((aligned(16))) float smemB[];
     float* Tf = smemB;                                 // [WGT][3 pieces][4 k-steps][64 lanes][8 bf16]
     float* Mf = Tf + WGT * TBW;                        // [WGT][MK][64]
     float* k0s = Mf + WGT * MK * 64;                   // [WGT*16]
-    const int grp = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int u, bx;
-    unit_block(xcd_map, nx, U, u, bx);
-    if (u >= U) return;                                // block-uniform
+    const int u = blockIdx.y, bx = blockIdx.x, grp = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int j0 = grp * WGT;                          // first w tile of this group
     const int ntile = min(WGT, NW16 - j0);             // w tiles this group really has
@@ -580,13 +551,11 @@ static size_t passB_lds() {
 
 int launch_passB(explainn_ctx* c, int B, hipStream_t s) {
     const int tiles = (B + 15) / 16;
-    const int nx = (tiles + 4 * PB_BTW - 1) / (4 * PB_BTW), xm = fc_xcd();
+    const int nx = (tiles + 4 * PB_BTW - 1) / (4 * PB_BTW);
 #define CALL(N)                                                                                  \
-    hipLaunchKernelGGL(passB_kernel<N>,                                                          \
-                       (xm ? dim3(nx * ((c->U + 7) & ~7), 1, fc_ng(N)) : dim3(nx, c->U, fc_ng(N))), \
-                       dim3(256), passB_lds<N>() + fc_ldspad(), s, c->ext, c->alpha,             \
-                       c->shift, c->dz, c->bits, c->Ttf, c->Mff, c->k0p, c->mug, c->sig1, c->dy,    \
-                       c->S12p, c->n, c->Bs, B, c->U, xm, nx)
+    hipLaunchKernelGGL(passB_kernel<N>, dim3(nx, c->U, fc_ng(N)), dim3(256), passB_lds<N>(), s,  \
+                       c->ext, c->alpha, c->shift, c->dz, c->bits, c->Ttf, c->Mff, c->k0p, c->mug,  \
+                       c->sig1, c->dy, c->S12p, c->n, c->Bs, B)
     NQ_DISPATCH(c->NQ, CALL);
 #undef CALL
     LAUNCH_CHECK();

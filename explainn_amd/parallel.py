@@ -88,8 +88,12 @@ class GradAllReduce:
             return self.flat
         if work is None:
             return self()
-        self._reduce(self.flat[:self.split])
+        # the head slice (conv_w, conv_b, bn1_w, bn1_b) goes to RCCL's stream as well: enqueued there
+        # behind an event of the launch stream, so the tail reduce still in flight and this one
+        # queue up on RCCL's side while the launch stream only waits once, for both
+        head = self._reduce(self.flat[:self.split], async_op=True)
         work.wait()
+        head.wait()
         if not self.native_avg:
             self.flat.div_(self.n)
         return self.flat

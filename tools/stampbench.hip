@@ -57,7 +57,7 @@ int main() {
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
         if (rep) report("qmom", QCH * U, 4, ms);
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((fc_fwd_kernel<26, 2>), dim3(4, U), dim3(256), fc_fwd_lds<26>(), 0, ext, alpha, shift, A2f, sh2, V2, bits, z, (const uint8_t*)nullptr, 19661u, 1.4285715f, 1u, 2u, fz, fz, fz, fz, fz, o, n, Bs, B, U, (const uint32_t*)nullptr, 0, 4);
+        hipLaunchKernelGGL((fc_fwd_kernel<26, 2>), dim3(4, U), dim3(256), fc_fwd_lds<26>(), 0, ext, alpha, shift, A2f, sh2, V2, bits, z, (const uint8_t*)nullptr, 19661u, 1.4285715f, 1u, 2u, fz, fz, fz, fz, fz, o, n, Bs, B, U, (const uint32_t*)nullptr);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
         if (rep) report("fc_fwd", 4 * U * 4, 5, ms);
         CK(hipEventRecord(e0));
@@ -65,7 +65,7 @@ int main() {
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
         if (rep) report("passA", ACH * U, 4, ms);
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(passB_kernel<26>, dim3(4, U, 1), dim3(256), passB_lds<26>(), 0, ext, alpha, shift, dz, bits, Tt, M, k0p, mug, sig1, dy, S12p, n, Bs, B, U, 0, 4); // (tables passed as fragment-ordered stand-ins)
+        hipLaunchKernelGGL(passB_kernel<26>, dim3(4, U, 1), dim3(256), passB_lds<26>(), 0, ext, alpha, shift, dz, bits, Tt, M, k0p, mug, sig1, dy, S12p, n, Bs, B); // (tables passed as fragment-ordered stand-ins)
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
         if (rep) report("passB", 4 * U * 4, 6, ms);
     }
@@ -82,12 +82,12 @@ int main() {
         double* qbar = (double*)dalloc((size_t)U * NS * 8); float* A2 = (float*)dalloc((size_t)U * 100 * NS * 4);
         float* sig2 = (float*)dalloc(U * 100 * 4); std::vector<float> ones(U * 100, 1.f); CK(hipMemcpy(sig2, ones.data(), U * 100 * 4, hipMemcpyHostToDevice));
         float* md = (float*)dalloc((size_t)U * 100 * n * 4 + 4096);
-        size_t cps = (size_t)(NT * 16 + k * 5) * 8 + (size_t)(PW + NW) * 64 * 4;
+        size_t cps = (size_t)(NT * 16 + k * 5) * 16 + (size_t)(19 + 10) * 64 * 4;
         for (int rep = 0; rep < 2; ++rep) {
             CK(hipEventRecord(e0));
-            hipLaunchKernelGGL(conv_pool_kernel<19>, dim3(16 * 2, U4 / 2), dim3(64), cps, 0, pk2, nmask, (const float2*)lut, Wt, alpha, U, ext, idx, n, Bs, PW, NW, 2);
+            hipLaunchKernelGGL(conv_pool_kernel<19>, dim3(16 * 4, U4 / 4), dim3(64), cps, 0, pk2, nmask, (const float4*)lut, Wt, alpha, U, ext, idx, n, Bs, PW, NW, 4);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
-            if (rep) report("conv_pool", 16 * 2 * (U4 / 2), 3, ms);
+            if (rep) report("conv_pool", 16 * 4 * (U4 / 4), 3, ms);
             CK(hipEventRecord(e0));
             hipLaunchKernelGGL(conv_bwd_kernel<19>, dim3(8, U), dim3(64), (size_t)(PW + NW) * 256 + 128 + 64, 0, dy, idx, pk2, nmask, Dspp, U, n, Bs, PW, NW, (PW + NW) * 64, B);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
