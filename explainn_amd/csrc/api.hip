@@ -68,8 +68,6 @@ void carve(explainn_ctx* c, Carver& cv) {
     cv.take(&c->EQp, U * c->ACH * FC_H * NS);
     cv.take(&c->Sep, U * c->ACH * FC_H);
     cv.take(&c->EQs, U * FC_H * NS);
-    cv.take(&c->Tt, (U * FC_H + 2) * NS);
-    cv.take(&c->M, (U * NS + 2) * NS);
     cv.take(&c->Ttf, U * fc_nw16(c->NQ) * 3 * 4 * 256);          // bf16 x 3 pieces (fc.hip passB)
     cv.take(&c->Mff, U * fc_nw16(c->NQ) * 4 * fc_nw16(c->NQ) * 64);
     cv.take(&c->k0p, U * NS);

@@ -27,8 +27,8 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
     const float* __restrict__ EQp, const float* __restrict__ Sep, const float* __restrict__ A2,
     const float* __restrict__ sh2, const float* __restrict__ sig2, const float* __restrict__ fc1_w,
     const float* __restrict__ fc2_w, const float* __restrict__ g2, const double* __restrict__ qbar,
-    const float* __restrict__ VC, float* __restrict__ Tt, float* __restrict__ Ttf,
-    float* __restrict__ M, float* __restrict__ Mff, float* __restrict__ k0p, float* __restrict__ g_fc2_w, float* __restrict__ g_bn2_w,
+    const float* __restrict__ VC, float* __restrict__ Ttf,
+    float* __restrict__ Mff, float* __restrict__ k0p, float* __restrict__ g_fc2_w, float* __restrict__ g_bn2_w,
     float* __restrict__ g_bn2_b, float* __restrict__ g_fc1_b, float* __restrict__ g_fc1_w, int n,
     int NS, int NW16, int B, int ACH, float scale) {
     extern __shared__ float fsm[];
@@ -100,53 +100,46 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
         md2s[r] = (float)(db2 / (double)B);
         md2hs[r] = (float)(dg2 / (double)B);
         cfs[r] = (float)((dg2 / (double)B) / sg);
-        svl[r] = (float)v2; gsl[r] = g2[ch]; sgl[r] = (float)sg;
+        svl[r] = (float)v2; gsl[r] = (float)((double)g2[ch] / sg); sgl[r] = (float)((double)B / sg);
     }
     __syncthreads();
     STAMP(2);
-    // M[v][w] = sum_r cf[r] V1[r][v] A2[r][w] on the fp32 MFMA (its consumer passB is fp32): one 32x32
-    // tile per wave, K = 100 channels = 50 steps, LDS operands read ten steps ahead.  (As an fp64
-    // VALU loop this phase was LDS-latency bound: 10 K cycles of the block's 36 K.)
+    // M[v][w] = sum_r cf[r] V1[r][v] A2[r][w] on the fp32 MFMA (its consumer passB is fp32), in 16x16
+    // tiles of v_mfma_f32_16x16x4_f32, one tile per wave (4 tiles at n <= 32), K = 100 channels = 25
+    // steps with all operands read ahead.  (One 32x32x2 tile on ONE wave -- 50 dependent 64-cycle
+    // steps plus a 16-value scattered epilogue -- was the block's critical path: every other wave sat
+    // at the barrier below for 12 K of the block's 34 K cycles.  As an fp64 VALU loop: worse still.)
+    const int NT2 = NW16;
+    const int ntile_m = NT2 * NT2;
     {
-        const int wave = tid >> 6, lane = tid & 63, rc = lane & 31, kk = lane >> 5;
-        const int NT2 = (NS + 31) >> 5;
-        // one wave per tile (splitting the single tile of n <= 32 over four waves with an LDS
-        // reduction made the isolated kernel faster and the pipeline 5 us slower: not kept)
-        for (int tile = wave; tile < NT2 * NT2; tile += 16) {
+        const int wave = tid >> 6, lane = tid & 63, c = lane & 15, gq = lane >> 4;
+        for (int tile = wave; tile < ntile_m; tile += 16) {
             const int vt = tile / NT2, wt = tile % NT2;
-            const int va = 32 * vt + rc, wb = 32 * wt + rc;
+            const int va = 16 * vt + c, wb = 16 * wt + c;
             const bool alive = va < n, blive = wb < n;
             const float* acol = V1s + min(va, n - 1);
             const float* bcol = A2s + min(wb, n - 1);
-            f32x16b acc;
+            f32x4b acc = f32x4b{0.f, 0.f, 0.f, 0.f};
+            // five steps' operands at a time: the block must stay at <= 64 VGPRs (two blocks per CU)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+            for (int q0 = 0; q0 < FC_H / 4; q0 += 5) {
+                float av[5], bv[5];
 #pragma unroll
-            for (int s0 = 0; s0 < FC_H / 2; s0 += 10) {
-                float av[10], bv[10];
-#pragma unroll
-                for (int q = 0; q < 10; ++q) {
-                    const int r = 2 * (s0 + q) + kk;
+                for (int q = 0; q < 5; ++q) {
+                    const int r = 4 * (q0 + q) + gq;
                     av[q] = cfs[r] * acol[r * ld];
                     bv[q] = bcol[r * ld];
                 }
 #pragma unroll
-                for (int q = 0; q < 10; ++q)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(alive ? av[q] : 0.f, blive ? bv[q] : 0.f,
-                                                               acc, 0, 0, 0);
+                for (int q = 0; q < 5; ++q)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(alive ? av[q] : 0.f, blive ? bv[q] : 0.f, acc, 0, 0, 0);
             }
-            if (wb < NS) {
+            // D[v][w]: rows v = 16vt + 4gq + i, column wb; Mff in passB's k order (j', i'): v = 16j' + 4g + i'
 #pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    const int v = 32 * vt + (g & 3) + 8 * (g >> 2) + 4 * kk;
-                    if (v < NS) {
-                        M[(size_t)u * NS * NS + (size_t)v * NS + wb] = acc[g];
-                        if (v < 16 * NW16 && wb < 16 * NW16)       // k order (j', i'): v = 16j' + 4g + i'
-                            Mff[(((size_t)u * NW16 + (wb >> 4)) * (4 * NW16) + 4 * (v >> 4) + (v & 3)) * 64 +
-                                16 * ((v >> 2) & 3) + (wb & 15)] = acc[g];
-                        if (v < n && wb < n) Ms[v * n + wb] = acc[g];
-                    }
-                }
+            for (int i = 0; i < 4; ++i) {
+                const int v = 16 * vt + 4 * gq + i;
+                Mff[(((size_t)u * NW16 + wt) * (4 * NW16) + 4 * vt + i) * 64 + 16 * gq + c] = acc[i];
+                if (v < n && wb < n) Ms[v * n + wb] = acc[i];
             }
         }
     }
@@ -154,7 +147,7 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
     // dV1 and T do not need M: the waves that had no M tile above do this loop while the tile waves
     // are still in their MFMA chains (with everybody taking an equal share the block waited for
     // wave 0 to finish its tile AND its share)
-    const int busy = min(((NS + 31) >> 5) * ((NS + 31) >> 5), 8) * 64;     // threads of the tile waves
+    const int busy = min(ntile_m, 8) * 64;             // threads of the tile waves
     for (int e = tid - busy; e < FC_H * NS; e += 1024 - busy) {
         if (e < 0) break;                              // tile waves skip
         const int r = e / NS, w = e % NS;
@@ -163,16 +156,14 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
         float tv = 0.f;
         if (w < n) {
             tv = (float)(sv * (double)A2s[r * ld + w]);
-            double hq = (double)VCl[r * ld + w];       // (V1.C)[r][w], computed once by prep2
-            const double sg = (double)sgl[r];
-            hq *= (double)B / sg;
-            const double val = ((double)gsl[r] / sg) *
+            // (V1.C)[r][w], computed once by prep2, times B / sigma2 (per-channel, from LDS)
+            const double hq = (double)VCl[r * ld + w] * (double)sgl[r];
+            const double val = (double)gsl[r] *
                                (sv * (double)EQl[r * ld + w] -
                                 (double)md2s[r] * (double)B * qbd[w] -
                                 (double)md2hs[r] * hq);
             g_fc1_w[ch * n + w] = (float)val;
         }
-        Tt[ch * NS + w] = tv;
         {
             // T[r][w] as three bf16 pieces (hi + mid + lo = tv exactly) in the A-fragment order of
             // v_mfma_f32_16x16x32_bf16: lane 16((r>>3)&3) + (w&15), element r&7 of k-step r>>5
@@ -208,8 +199,8 @@ __global__ __launch_bounds__(1024) void mid_big_kernel(
     const float* __restrict__ EQp, const float* __restrict__ Sep, const float* __restrict__ A2,
     const float* __restrict__ sh2, const float* __restrict__ sig2, const float* __restrict__ fc1_w,
     const float* __restrict__ fc2_w, const float* __restrict__ g2, const double* __restrict__ qbar,
-    const float* __restrict__ VC, float* __restrict__ EQs, float* __restrict__ Tt,
-    float* __restrict__ Ttf, float* __restrict__ M, float* __restrict__ Mff,
+    const float* __restrict__ VC, float* __restrict__ EQs,
+    float* __restrict__ Ttf, float* __restrict__ Mff,
     float* __restrict__ k0p, float* __restrict__ g_fc2_w, float* __restrict__ g_bn2_w,
     float* __restrict__ g_bn2_b, float* __restrict__ g_fc1_b, float* __restrict__ g_fc1_w, int n,
     int NS, int NW16, int B, int ACH, float scale) {
@@ -315,7 +306,6 @@ __global__ __launch_bounds__(1024) void mid_big_kernel(
                 for (int g = 0; g < 16; ++g) {
                     const int v = 32 * vt + (g & 3) + 8 * (g >> 2) + 4 * kk;
                     if (v < NS) {
-                        M[(size_t)u * NS * NS + (size_t)v * NS + wb] = acc[g];
                         if (v < 16 * NW16 && wb < 16 * NW16)       // k order (j', i'): v = 16j' + 4g + i'
                             Mff[(((size_t)u * NW16 + (wb >> 4)) * (4 * NW16) + 4 * (v >> 4) + (v & 3)) * 64 +
                                 16 * ((v >> 2) & 3) + (wb & 15)] = acc[g];
@@ -340,7 +330,6 @@ __global__ __launch_bounds__(1024) void mid_big_kernel(
                                 (double)md2hs[r] * hq);
             g_fc1_w[ch * n + w] = (float)val;
         }
-        Tt[ch * NS + w] = tv;
         {
             // T[r][w] as three bf16 pieces (hi + mid + lo = tv exactly) in the A-fragment order of
             // v_mfma_f32_16x16x32_bf16: lane 16((r>>3)&3) + (w&15), element r&7 of k-step r>>5
@@ -376,7 +365,7 @@ int launch_mid_bwd(explainn_ctx* c, const explainn_params* p, const explainn_gra
     if (c->n <= 72) {
         hipLaunchKernelGGL(mid_fused_kernel, dim3(c->U), dim3(1024), mid_fused_lds(c->n), s, c->EQp,
                            c->Sep, c->A2, c->sh2, c->sig2, p->fc1_w, p->fc2_w, p->bn2_w, c->qbar,
-                           c->VC, c->Tt, c->Ttf, c->M, c->Mff, c->k0p, g->fc2_w, g->bn2_w, g->bn2_b,
+                           c->VC, c->Ttf, c->Mff, c->k0p, g->fc2_w, g->bn2_w, g->bn2_b,
                            g->fc1_b, g->fc1_w, c->n, c->NS, fc_nw16(c->NQ), B, c->ACH,
                            c->fwd_scale);
         LAUNCH_CHECK();
@@ -384,7 +373,7 @@ int launch_mid_bwd(explainn_ctx* c, const explainn_params* p, const explainn_gra
     }
     hipLaunchKernelGGL(mid_big_kernel, dim3(c->U), dim3(1024), mid_big_lds(c->n), s, c->EQp, c->Sep,
                        c->A2, c->sh2, c->sig2, p->fc1_w, p->fc2_w, p->bn2_w, c->qbar, c->VC, c->EQs,
-                       c->Tt, c->Ttf, c->M, c->Mff, c->k0p, g->fc2_w, g->bn2_w, g->bn2_b, g->fc1_b,
+                       c->Ttf, c->Mff, c->k0p, g->fc2_w, g->bn2_w, g->bn2_b, g->fc1_b,
                        g->fc1_w, c->n, c->NS, fc_nw16(c->NQ), B, c->ACH,
                        c->fwd_scale);
     LAUNCH_CHECK();

@@ -74,11 +74,9 @@ struct explainn_ctx {
     float* EQp;           // [U][ACH][NS][100]  passA's partial sums, w-major (four rows r = one 16-byte store)
     float* Sep;           // [U][ACH][100]
     float* EQs;           // [U][100][NS]
-    float* Tt;            // [U][100][NS]
     float* Ttf;           // [U][NW16][3][4][64][8] bf16: T as three bf16 pieces in the A-fragment order of
                           //                        v_mfma_f32_16x16x32_bf16 (passB copies it to LDS)
     float* Mff;           // [U][NW16][4 NW16][64] M in A-fragment order, k order (j',i') -> v = 16j'+4g+i' 
-    float* M;             // [U][NS][NS]
     float* k0p;           // [U][NS]
     float* dy;            // [U4][n][Bs]
     float* S12p;          // [U][NG][Bs/16][2] per (w-tile group, 16-sequence tile): sum dy, sum dy*chat

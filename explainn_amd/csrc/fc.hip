@@ -115,57 +115,49 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(
         if (it == 0) STAMP(2);
         float zp = 0.f;
         uint32_t words[4] = {0u, 0u, 0u, 0u};
-        // channel tiles two at a time: two independent accumulator chains
+        // all seven channel tiles first (seven independent accumulator chains, k-step outermost: one
+        // operand read per tile and step), then the lane-local epilogue of all 28 channels
+        f32x4 acc[FC_MT];
 #pragma unroll
-        for (int t0 = 0; t0 < FC_MT; t0 += 2) {
-            f32x4 acc[2];
+        for (int t = 0; t < FC_MT; ++t) {
+            const float4 v = *reinterpret_cast<const float4*>(&sh2s[16 * t + 4 * g]);
+            acc[t][0] = v.x; acc[t][1] = v.y; acc[t][2] = v.z; acc[t][3] = v.w;
+        }
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                const int t = min(t0 + tt, FC_MT - 1);
-                const float4 v = *reinterpret_cast<const float4*>(&sh2s[16 * t + 4 * g]);
-                acc[tt][0] = v.x; acc[tt][1] = v.y; acc[tt][2] = v.z; acc[tt][3] = v.w;
+        for (int sq = 0; sq < NK4Q; ++sq) {
+#pragma unroll
+            for (int t = 0; t < FC_MT; ++t) {
+                const float4 a4 = Af[(t * NK4Q + sq) * 64 + lane];
+                const float aa[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * sq + e < NK4) acc[t] = MFMA16(aa[e], qf[4 * sq + e], acc[t]);
             }
+        }
 #pragma unroll
-            for (int sq = 0; sq < NK4Q; ++sq) {
-                const float4 a0 = Af[(t0 * NK4Q + sq) * 64 + lane];
-                const float4 a1v = (t0 + 1 < FC_MT) ? Af[((t0 + 1) * NK4Q + sq) * 64 + lane] : a0;
-                const float a0a[4] = {a0.x, a0.y, a0.z, a0.w}, a1a[4] = {a1v.x, a1v.y, a1v.z, a1v.w};
+        for (int t = 0; t < FC_MT; ++t) {
+            const float4 v2 = *reinterpret_cast<const float4*>(&v2s[16 * t + 4 * g]);
+            const float v2a[4] = {v2.x, v2.y, v2.z, v2.w};
+            uint32_t nib = 0u;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int s = 4 * sq + e;
-                    if (s < NK4) {
-                        acc[0] = MFMA16(a0a[e], qf[s], acc[0]);
-                        if (t0 + 1 < FC_MT) acc[1] = MFMA16(a1a[e], qf[s], acc[1]);
-                    }
+            for (int j = 0; j < 4; ++j) {
+                const float y = acc[t][j];
+                bool pos = y > 0.f;
+                if (MODE == 2) {
+                    uint32_t rnd;
+                    if ((j & 1) == 0) { rs ^= rs << 13; rs ^= rs >> 17; rs ^= rs << 5; rnd = rs & 0xffffU; }
+                    else rnd = rs >> 16;
+                    pos = pos && (rnd >= thresh16);
+                } else if (MODE == 3) {
+                    const int r = 16 * t + 4 * g + j;
+                    pos = pos && (km[r < FC_H ? r : 0] != 0);
                 }
+                const float av = pos ? y * scale : 0.f;
+                zp = fmaf(v2a[j], av, zp);
+                nib |= (pos ? 1u : 0u) << j;
             }
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                const int t = t0 + tt;
-                if (t >= FC_MT) break;
-                const float4 v2 = *reinterpret_cast<const float4*>(&v2s[16 * t + 4 * g]);
-                const float v2a[4] = {v2.x, v2.y, v2.z, v2.w};
-                uint32_t nib = 0u;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float y = acc[tt][j];
-                    bool pos = y > 0.f;
-                    if (MODE == 2) {
-                        uint32_t rnd;
-                        if ((j & 1) == 0) { rs ^= rs << 13; rs ^= rs >> 17; rs ^= rs << 5; rnd = rs & 0xffffU; }
-                        else rnd = rs >> 16;
-                        pos = pos && (rnd >= thresh16);
-                    } else if (MODE == 3) {
-                        const int r = 16 * t + 4 * g + j;
-                        pos = pos && (km[r < FC_H ? r : 0] != 0);
-                    }
-                    const float av = pos ? y * scale : 0.f;
-                    zp = fmaf(v2a[j], av, zp);
-                    nib |= (pos ? 1u : 0u) << j;
-                }
-                // channel r = 16t + 4g + j is bit (r & 31) of word r >> 5
-                words[t >> 1] |= nib << (16 * (t & 1) + 4 * g);
-            }
+            // channel r = 16t + 4g + j is bit (r & 31) of word r >> 5
+            words[t >> 1] |= nib << (16 * (t & 1) + 4 * g);
         }
         if (it == 0) STAMP(3);
         // the four lane groups of a sequence hold disjoint channel sets: merge across g

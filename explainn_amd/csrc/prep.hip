@@ -135,109 +135,109 @@ int launch_prep1(explainn_ctx* c, const explainn_params* p, int B, bool train, h
 // super-tile's loads are in flight while the current one feeds the matrix core.
 // ---------------------------------------------------------------------------------------------
 typedef float f32x16q __attribute__((ext_vector_type(16)));
+typedef float f32x4q __attribute__((ext_vector_type(4)));
 #define QT_LD 65
+#define QS_LD 66          // row stride of the small-n tile: operand reads (16 rows x 2 columns per 32 lanes) conflict-free
 
+// n <= 32: v_mfma_f32_16x16x4_f32, the upper triangle of the (at most 2 x 2) tile grid; all 16 k-steps
+// of a 64-sequence super-tile unrolled, so the LDS operand reads run far ahead of the matrix core.
+// (The 32x32x2 version read two operands per 64-cycle MFMA eight steps ahead and still spent 9 K
+// cycles per super-tile for 2 K cycles of MFMA.)  The four rows a lane holds of a tile are
+// consecutive, so the mirrored half of the symmetric matrix is written with 16-byte stores.
 template <int NQ>
 __global__ __launch_bounds__(64) void qmom_kernel(
     const float* __restrict__ ext, const float* __restrict__ alpha,
     const float* __restrict__ shift, float* __restrict__ qs0, float* __restrict__ S1p,
     float* __restrict__ S2p, int n, int Bs, int B, int QCH) {
-    constexpr int NS = ns_stride(NQ), NWT = (NQ + 31) / 32;
-    __shared__ float tA[32 * QT_LD];
-    __shared__ float tB[NWT > 1 ? 32 * QT_LD : 1];
+    constexpr int NS = ns_stride(NQ), NW16 = fc_nw16(NQ), ROWS = 16 * NW16;
+    constexpr int NP = NW16 * (NW16 + 1) / 2;
+    __shared__ float tq[ROWS * QS_LD];
     const int u = blockIdx.y, ch = blockIdx.x, lane = threadIdx.x;
-    const int wt = blockIdx.z / NWT, wt2 = blockIdx.z % NWT;
-    const bool same = wt == wt2;
-    const int rc = lane & 31, kk = lane >> 5;
+    const int c = lane & 15, g = lane >> 4;
     const int per = ((((B + QCH - 1) / QCH) + 63) / 64) * 64;
     const int bbeg = ch * per, bend = min(B, bbeg + per);
     const float a1 = alpha[u], sh1 = shift[u];
-    const float* eu = ext + (size_t)u * n * Bs;
-    const int wB = wt2 * 32 + rc;
-    const float sBraw = eu[(size_t)min(wB, n - 1) * Bs];
-    const float sB = (wB < n) ? qval(a1, sBraw, sh1) : 0.f;                  // q of sequence 0
-    if (ch == 0 && wt == 0 && kk == 0 && wB < NS) qs0[(size_t)u * NS + wB] = sB;
-    const float sAraw = eu[(size_t)min(wt * 32 + rc, n - 1) * Bs];
-    const float sA = (wt * 32 + rc < n) ? qval(a1, sAraw, sh1) : 0.f;     // shift of the A rows
-    f32x16q acc;
+    const float* __restrict__ eu = ext + (size_t)u * n * Bs;
+    // shift = q of sequence 0 (for conditioning; any constant per row would do)
+    float s0[ROWS];
 #pragma unroll
-    for (int g = 0; g < 16; ++g) acc[g] = 0.f;
-    float s1 = 0.f;
-    float ra[32], rb[NWT > 1 ? 32 : 1];
+    for (int i = 0; i < ROWS; ++i) s0[i] = eu[min(i, n - 1) * Bs];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) s0[i] = i < n ? qval(a1, s0[i], sh1) : 0.f;
+    if (ch == 0 && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i)
+            if (i < NS) qs0[(size_t)u * NS + i] = s0[i];
+    }
+    f32x4q acc[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) acc[p] = f32x4q{0.f, 0.f, 0.f, 0.f};
+    float s1[NW16];
+#pragma unroll
+    for (int j = 0; j < NW16; ++j) s1[j] = 0.f;
+    float rq[ROWS];
     auto fetch = [&](int b0) {
         const int b = b0 + lane;
         const bool live = b < bend;
         const int bcl = live ? b : bbeg;
-        // all row loads are issued together (unconditional, clamped addresses), pinned, then used
 #pragma unroll
-        for (int i = 0; i < 32; ++i) ra[i] = eu[(size_t)min(wt * 32 + i, n - 1) * Bs + bcl];
-        if (NWT > 1 && !same) {
+        for (int i = 0; i < ROWS; ++i) rq[i] = eu[min(i, n - 1) * Bs + bcl];
 #pragma unroll
-            for (int i = 0; i < (NWT > 1 ? 32 : 1); ++i) rb[i] = eu[(size_t)min(wt2 * 32 + i, n - 1) * Bs + bcl];
-        }
+        for (int i = 0; i < ROWS; ++i) KEEP(rq[i]);
 #pragma unroll
-        for (int i = 0; i < 32; ++i) KEEP(ra[i]);
-#pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            const int w = wt * 32 + i;
-            ra[i] = (live && w < n) ? qval(a1, ra[i], sh1) : 0.f;
-        }
-        if (NWT > 1 && !same) {
-#pragma unroll
-            for (int i = 0; i < (NWT > 1 ? 32 : 1); ++i) KEEP(rb[i]);
-#pragma unroll
-            for (int i = 0; i < (NWT > 1 ? 32 : 1); ++i) {
-                const int w = wt2 * 32 + i;
-                rb[i] = (live && w < n) ? qval(a1, rb[i], sh1) : 0.f;
-            }
-        }
+        for (int i = 0; i < ROWS; ++i) rq[i] = (live && i < n) ? qval(a1, rq[i], sh1) - s0[i] : 0.f;
     };
     STAMP(0);
     if (bbeg < bend) fetch(bbeg);
     for (int b0 = bbeg; b0 < bend; b0 += 64) {
 #pragma unroll
-        for (int i = 0; i < 32; ++i) tA[i * QT_LD + lane] = ra[i];
+        for (int i = 0; i < ROWS; ++i) tq[i * QS_LD + lane] = rq[i];
         if (b0 == bbeg) STAMP(1);
-        if (NWT > 1 && !same) {
-#pragma unroll
-            for (int i = 0; i < (NWT > 1 ? 32 : 1); ++i) tB[i * QT_LD + lane] = rb[i];
-        }
         if (b0 + 64 < bend) fetch(b0 + 64);           // in flight during the MFMAs below
-        const float* srcB = (NWT > 1 && !same) ? tB : tA;
-        // Always the full 32 k-steps of a super-tile, eight at a time with their LDS operands read
-        // first (columns past the chunk end are zero): with a runtime trip count every step was
-        // "read LDS, wait, one MFMA" -- ~440 cycles each instead of the MFMA's 64.
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int s0 = 0; s0 < 32; s0 += 8) {
-            float av[8], bv[8];
+        for (int s = 0; s < 16; ++s) {
+            float av[NW16];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int col = 2 * (s0 + q) + kk;
-                av[q] = tA[rc * QT_LD + col];
-                bv[q] = (NWT > 1 && !same) ? srcB[rc * QT_LD + col] : av[q];
+            for (int j = 0; j < NW16; ++j) {
+                av[j] = tq[(16 * j + c) * QS_LD + 4 * s + g];
+                s1[j] += av[j];
             }
+            int p = 0;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int col = 2 * (s0 + q) + kk;
-                const bool live = b0 + col < bend;
-                const float a = (live && wt * 32 + rc < n) ? av[q] - sA : 0.f;
-                const float bq = (live && wB < n) ? bv[q] - sB : 0.f;
-                s1 += bq;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc, 0, 0, 0);
-            }
+            for (int j = 0; j < NW16; ++j)
+#pragma unroll
+                for (int j2 = j; j2 < NW16; ++j2, ++p)
+                    acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], av[j2], acc[p], 0, 0, 0);
         }
+        __builtin_amdgcn_wave_barrier();
     }
     STAMP(2);
-    if (wB < NS) {
+    // D[w][w'] of tile (j, j2): lane holds rows w = 16j + 4g + i, column w' = 16j2 + c
+    float* out = S2p + ((size_t)u * QCH + ch) * NS * NS;
+    int p = 0;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const int w = wt * 32 + (g & 3) + 8 * (g >> 2) + 4 * kk;
-            if (w < NS) S2p[(((size_t)u * QCH + ch) * NS + w) * NS + wB] = acc[g];
+    for (int j = 0; j < NW16; ++j)
+#pragma unroll
+        for (int j2 = j; j2 < NW16; ++j2, ++p) {
+            const int w = 16 * j + 4 * g, wp = 16 * j2 + c;
+            if (wp < NS && w < NS) {
+                // S2[w'][w .. w+3] (symmetric): one 16-byte store; NS is a multiple of 4
+                *reinterpret_cast<float4*>(&out[(size_t)wp * NS + w]) =
+                    make_float4(acc[p][0], acc[p][1], acc[p][2], acc[p][3]);
+                if (j2 != j) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) out[(size_t)(w + i) * NS + wp] = acc[p][i];
+                }
+            }
         }
-    }
-    if (wt == 0) {
-        s1 += __shfl_xor(s1, 32, 64);
-        if (kk == 0 && wB < NS) S1p[((size_t)u * QCH + ch) * NS + wB] = s1;
+#pragma unroll
+    for (int j = 0; j < NW16; ++j) {
+        float sv = s1[j];
+        sv += __shfl_xor(sv, 16, 64);
+        sv += __shfl_xor(sv, 32, 64);
+        const int w = 16 * j + c;
+        if (g == 0 && w < NS) S1p[((size_t)u * QCH + ch) * NS + w] = sv;
     }
     STAMP(3);
 }
@@ -444,7 +444,9 @@ __global__ __launch_bounds__(1024) void prep2_kernel(
             }
         }
         // combine the chunk partials (fixed order -> deterministic), eight loads in flight; the last
-        // threads take this so that it overlaps the staging above
+        // threads take this so that it overlaps the staging above.  (Issuing these, the covariance
+        // partials below and V1 in ONE batch per thread was tried: shorter waves, longer kernel --
+        // +6 us on the step with the same change in mid_fused.)
         for (int w = NT - 1 - tid; w < n; w += NT) {
             double s1 = 0;
             for (int c0 = 0; c0 < QCH; c0 += 8) {

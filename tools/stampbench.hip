@@ -97,7 +97,7 @@ int main() {
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
             if (rep) report("prep2", U * 16, 4, ms);
             CK(hipEventRecord(e0));
-            hipLaunchKernelGGL(mid_fused_kernel, dim3(U), dim3(1024), mid_fused_lds(n), 0, EQp, Sep, A2, sh2, sig2, fc1_w, V2, sh2, qbar, VC, Tt, Tt, M, M, k0p, md, md, md, md, md, n, NS, NW16, B, ACH, 1.4285715f);
+            hipLaunchKernelGGL(mid_fused_kernel, dim3(U), dim3(1024), mid_fused_lds(n), 0, EQp, Sep, A2, sh2, sig2, fc1_w, V2, sh2, qbar, VC, Tt, M, k0p, md, md, md, md, md, n, NS, NW16, B, ACH, 1.4285715f);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
             if (rep) report("mid_fused", U * 16, 6, ms);
         }
