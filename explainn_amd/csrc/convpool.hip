@@ -21,17 +21,21 @@
 // The tables LUT[pair][t][code4] = (W[u0][c0][2t] + W[u0][c1][2t+1], same for u1),
 // c_i = (code4 >> 2i) & 3, are written by prep1 (prep.hip) from the current filters.
 
-// byte offset (x ESZ) of the 2-mer starting x bases into the window; x is compile-time after unrolling
+// LDS address of the table entry of the 2-mer starting x bases into the window (x is compile-time
+// after unrolling): the 4 code bits are shifted straight to their place in the byte offset and OR-ed
+// onto the table's base (which is aligned to the table size), one shift + one v_and_or_b32
 template <int ESZ>
-__device__ __forceinline__ uint32_t dimer_off(uint32_t w0, uint32_t w1, uint32_t w2, int x) {
+__device__ __forceinline__ uint32_t dimer_addr(uint32_t w0, uint32_t w1, uint32_t w2, int x, uint32_t base) {
+    constexpr int LG = ESZ == 16 ? 4 : 3;      // log2(ESZ)
+    static_assert(ESZ == 16 || ESZ == 8, "table entries are float4 or float2");
     const int bit = 2 * x;
-    uint32_t v;
-    if (bit + 4 <= 32) v = w0 >> bit;
-    else if (bit >= 32 && bit + 4 <= 64) v = w1 >> (bit - 32);
-    else if (bit >= 64) v = w2 >> (bit - 64);
-    else if (bit < 32) v = __funnelshift_r(w0, w1, bit);
-    else v = __funnelshift_r(w1, w2, bit - 32);
-    return (v & 0xfu) * (uint32_t)ESZ;
+    uint32_t v;                                 // the 4 code bits at bit positions LG..LG+3
+    if (bit + 4 <= 32) v = bit >= LG ? (w0 >> (bit - LG)) : (w0 << (LG - bit));
+    else if (bit >= 32 && bit + 4 <= 64) v = (bit - 32) >= LG ? (w1 >> (bit - 32 - LG)) : (w1 << (LG - (bit - 32)));
+    else if (bit >= 64) v = (bit - 64) >= LG ? (w2 >> (bit - 64 - LG)) : (w2 << (LG - (bit - 64)));
+    else if (bit < 32) v = __funnelshift_r(w0, w1, bit) << LG;
+    else v = __funnelshift_r(w1, w2, bit - 32) << LG;
+    return (v & (0xfu * ESZ)) | base;
 }
 
 // The gather + pooling of one wavefront: lane = sequence b, NU units (2 or 4), pooling windows
@@ -46,7 +50,7 @@ template <int NU> struct fvec;
 template <> struct fvec<2> { typedef float type __attribute__((ext_vector_type(2))); };
 template <> struct fvec<4> { typedef float type __attribute__((ext_vector_type(4))); };
 
-template <int K, int NU, typename Sink>
+template <int K, int NU, int CPW, typename Sink>
 __device__ __forceinline__ void conv_pool_windows(const void* L2, const void* Wp, uint32_t* pks,
                                                   uint32_t* nms, const uint32_t* __restrict__ pk2,
                                                   const uint32_t* __restrict__ nmask,
@@ -58,10 +62,15 @@ __device__ __forceinline__ void conv_pool_windows(const void* L2, const void* Wp
     constexpr int NT = (K + 1) / 2;             // 2-mer tables
     constexpr int NX = POOLW + 2 * (NT - 1);    // distinct 2-mer start offsets inside a window
     constexpr int SPAN = POOLW + K - 1;         // positions a pooling window reads
-    constexpr int CPW = 32;
+    typedef __attribute__((address_space(3))) fv lds_fv;
+    typedef __attribute__((address_space(3))) char lds_char;
     constexpr int PWC = ((POOLW * CPW + K + 15) >> 4) + 3, NWC = ((POOLW * CPW + K + 31) >> 5) + 2;
     const char* Lb = reinterpret_cast<const char*>(L2);
     const char* Wb = reinterpret_cast<const char*>(Wp);
+    // 32-bit LDS address of the 2-mer tables; the callers put them at the start of the dynamic LDS
+    // (aligned to the 16-entry table: the entry offset is OR-ed in)
+    const uint32_t lbase = (uint32_t)(size_t)(const lds_char*)Lb;
+    if (lbase & (16u * ESZ - 1u)) __builtin_trap();
     const uint32_t* pl = pks + lane;
     const uint32_t* nl = nms + lane;
     for (int wc = wbeg; wc < wend; wc += CPW) {
@@ -90,56 +99,75 @@ __device__ __forceinline__ void conv_pool_windows(const void* L2, const void* Wp
         }
         constexpr uint32_t HIMASK = SPAN > 32 ? ((SPAN >= 64) ? 0xffffffffu : ((1u << (SPAN - 32)) - 1u)) : 0u;
         constexpr uint32_t LOMASK = SPAN >= 32 ? 0xffffffffu : ((1u << SPAN) - 1u);
+        // the first tap pair initialises the sums (no zero + add), the table addresses are formed as
+        // 32-bit LDS addresses with the table offset in the instruction's immediate
         fv acc[POOLW];
-#pragma unroll
-        for (int i = 0; i < POOLW; ++i) acc[i] = fv(0.f);
         {
             uint32_t a8[NX];
 #pragma unroll
-            for (int x = 0; x < NX; ++x) a8[x] = dimer_off<ESZ>(w0, w1, w2, x);
+            for (int x = 0; x < NX; ++x) a8[x] = dimer_addr<ESZ>(w0, w1, w2, x, lbase);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
+            for (int i = 0; i < POOLW; ++i) acc[i] = *reinterpret_cast<const lds_fv*>((const lds_char*)(size_t)a8[i]);
+#pragma unroll
+            for (int t = 1; t < NT; ++t) {
 #pragma unroll
                 for (int i = 0; i < POOLW; ++i)
-                    acc[i] += *reinterpret_cast<const fv*>(Lb + t * 16 * ESZ + a8[i + 2 * t]);
+                    acc[i] += *reinterpret_cast<const lds_fv*>((const lds_char*)(size_t)a8[i + 2 * t] + t * 16 * ESZ);
             }
         }
         // N bases are packed as 'C': take the C tap back out wherever the mask says N.  Per lane and
         // per N base (a loop over the set bits; lanes without an N idle through it), instead of
         // sending the whole wavefront down a 19-reads-per-position path because one lane saw an N.
+        // The corrections are summed apart and subtracted once: with the sums themselves carried
+        // through the loop the compiler copied all of them twice per window, N or not.
         uint32_t r0 = nm0 & LOMASK, r1 = nm1 & HIMASK;
-        while (__any((r0 | r1) != 0u)) {
-            if ((r0 | r1) != 0u) {
-                int x;
-                if (r0) { x = __ffs(r0) - 1; r0 &= r0 - 1u; }
-                else { x = 32 + __ffs(r1) - 1; r1 &= r1 - 1u; }
+        if (__any((r0 | r1) != 0u)) {
+            fv corr[POOLW];
 #pragma unroll
-                for (int i = 0; i < POOLW; ++i) {
-                    const int j = x - i;                 // base x of the window is tap j of position i
-                    if (j >= 0 && j < K)
-                        acc[i] -= *reinterpret_cast<const fv*>(Wb + j * 5 * ESZ + ESZ);   // code 1 = C
+            for (int i = 0; i < POOLW; ++i) corr[i] = fv(0.f);
+            do {
+                if ((r0 | r1) != 0u) {
+                    int x;
+                    if (r0) { x = __ffs(r0) - 1; r0 &= r0 - 1u; }
+                    else { x = 32 + __ffs(r1) - 1; r1 &= r1 - 1u; }
+#pragma unroll
+                    for (int i = 0; i < POOLW; ++i) {
+                        const int j = x - i;                 // base x of the window is tap j of position i
+                        if (j >= 0 && j < K)
+                            corr[i] += *reinterpret_cast<const fv*>(Wb + j * 5 * ESZ + ESZ);   // code 1 = C
+                    }
                 }
-            }
+            } while (__any((r0 | r1) != 0u));
+#pragma unroll
+            for (int i = 0; i < POOLW; ++i) acc[i] -= corr[i];
         }
+        // pooled extreme: max or min by the (wave-uniform) sign, then the first position that holds it
+        // (the index chains of the NU units are interleaved: a compare and the select that reads
+        // its lane mask back to back cost two idle issue slots each)
         float ex[NU];
         int bi[NU];
 #pragma unroll
         for (int uu = 0; uu < NU; ++uu) {
-            float best = sg[uu] * acc[0][uu];
-            int bidx = 0;
+            float hi = acc[0][uu], lo = acc[0][uu];
 #pragma unroll
-            for (int i = 1; i < POOLW; ++i) {
-                const float v = sg[uu] * acc[i][uu];
-                if (v > best) { best = v; bidx = i; }          // strict: first index wins ties
-            }
-            ex[uu] = sg[uu] * best; bi[uu] = bidx;
+            for (int i = 1; i < POOLW; ++i) { hi = fmaxf(hi, acc[i][uu]); lo = fminf(lo, acc[i][uu]); }
+            ex[uu] = sg[uu] > 0.f ? hi : lo;
+            bi[uu] = POOLW - 1;
+        }
+#pragma unroll
+        for (int i = POOLW - 2; i >= 0; --i) {
+            bool eq[NU];
+#pragma unroll
+            for (int uu = 0; uu < NU; ++uu) eq[uu] = acc[i][uu] == ex[uu];
+#pragma unroll
+            for (int uu = 0; uu < NU; ++uu) bi[uu] = eq[uu] ? i : bi[uu];       // first index wins ties
         }
         sink(w, ex, bi);
     }
     }
 }
 
-template <int K>
+template <int K, int CPW>
 __global__ __launch_bounds__(64) void conv_pool_kernel(const uint32_t* __restrict__ pk2,
                                                        const uint32_t* __restrict__ nmask,
                                                        const float4* __restrict__ lut,
@@ -149,12 +177,13 @@ __global__ __launch_bounds__(64) void conv_pool_kernel(const uint32_t* __restric
                                                        uint8_t* __restrict__ idx, int n, int Bs,
                                                        int PW, int NW, int wsplit) {
     constexpr int NT = (K + 1) / 2;
-    extern __shared__ __attribute__((aligned(16))) uint32_t csm[];
+    extern __shared__ __attribute__((aligned(256))) uint32_t csm[];
     float4* L2 = reinterpret_cast<float4*>(csm);            // [NT][16]  2-mer sums of the unit quad
     float4* Wp = L2 + NT * 16;                              // [K][5]    per-tap table (N path)
     // the packed codes are staged per chunk of CPW pooling windows: ~7 KB of LDS per wave at any
-    // sequence length (the whole of a 1000-bp sequence was 26 KB and cost two thirds of the occupancy)
-    constexpr int CPW = 32;
+    // sequence length (the whole of a 1000-bp sequence was 26 KB and cost two thirds of the occupancy);
+    // CPW = 8 where a wave's share of the windows fits one such chunk (3.3 KB: the 32-window tile
+    // capped the C2 launch at 13 of its 19 waves per CU)
     constexpr int PWC = ((POOLW * CPW + K + 15) >> 4) + 3;
     uint32_t* pks = reinterpret_cast<uint32_t*>(Wp + K * 5); // [PWC][64]
     uint32_t* nms = pks + (size_t)PWC * 64;                  // [NWC][64]
@@ -192,12 +221,15 @@ __global__ __launch_bounds__(64) void conv_pool_kernel(const uint32_t* __restric
     for (int uu = 0; uu < 4; ++uu) sg[uu] = (quad * 4 + uu < U && gamma1[quad * 4 + uu] < 0.f) ? -1.f : 1.f;
     __syncthreads();
     STAMP(1);
-    conv_pool_windows<K, 4>(L2, Wp, pks, nms, pk2, nmask, sg, b, lane, wbeg, wend, Bs, PW, NW,
+    conv_pool_windows<K, 4, CPW>(L2, Wp, pks, nms, pk2, nmask, sg, b, lane, wbeg, wend, Bs, PW, NW,
                             [&](int w, const float (&e)[4], const int (&i)[4]) {
+                                // wave-uniform row pointers + one 32-bit lane offset (saddr stores)
+                                const uint32_t o = (uint32_t)(w * Bs + b), o4 = o * 4u;
 #pragma unroll
                                 for (int uu = 0; uu < 4; ++uu) {
-                                    const size_t o = ((size_t)(quad * 4 + uu) * n + w) * Bs + b;
-                                    ext[o] = e[uu]; idx[o] = (uint8_t)i[uu];
+                                    const size_t row = (size_t)(quad * 4 + uu) * n * Bs;
+                                    *reinterpret_cast<float*>(reinterpret_cast<char*>(ext + row) + o4) = e[uu];
+                                    (idx + row)[o] = (uint8_t)i[uu];
                                 }
                             });
     STAMP(2);
@@ -220,35 +252,48 @@ __global__ __launch_bounds__(64) void conv_pool_kernel(const uint32_t* __restric
                  return EXPLAINN_E_UNSUPPORTED;                                                \
     }
 
-static size_t conv_pool_lds(const explainn_ctx* c) {
+// window split and chunk length of the launch: four units per lane leave half the waves of a
+// two-unit version per window split, so the windows are split four ways where there are enough
+static int conv_pool_wsplit(const explainn_ctx* c) { return c->n >= 16 ? 4 : (c->n >= 8 ? 2 : 1); }
+static int conv_pool_cpw(const explainn_ctx* c) {
+    const int ws = conv_pool_wsplit(c);
+    return (c->n + ws - 1) / ws <= 8 ? 8 : 32;
+}
+
+static size_t conv_pool_lds(const explainn_ctx* c, int cpw) {
     const int NT = (c->k + 1) / 2;
     // tables + the chunk tiles [PWC + NWC][64] (see the kernel)
-    const int pwc = ((POOLW * 32 + c->k + 15) >> 4) + 3, nwc = ((POOLW * 32 + c->k + 31) >> 5) + 2;
+    const int pwc = ((POOLW * cpw + c->k + 15) >> 4) + 3, nwc = ((POOLW * cpw + c->k + 31) >> 5) + 2;
     return (size_t)(NT * 16 + c->k * 5) * sizeof(float4) + (size_t)(pwc + nwc) * 64 * 4;
 }
 
 int launch_conv_pool(explainn_ctx* c, const explainn_params* p, int B, hipStream_t s) {
-    // four units per lane: half the waves of the two-unit version per window split -> split the
-    // windows four ways where there are enough of them
-    const int wsplit = c->n >= 16 ? 4 : (c->n >= 8 ? 2 : 1);
+    const int wsplit = conv_pool_wsplit(c), cpw = conv_pool_cpw(c);
     const dim3 grid(((B + 63) / 64) * wsplit, c->Uq);
-    const size_t sm = conv_pool_lds(c);
+    const size_t sm = conv_pool_lds(c, cpw);
+#define ARGS grid, dim3(64), sm, s, c->pk2, c->nmask, reinterpret_cast<const float4*>(c->lut), c->Wt, \
+             p->bn1_w, c->U, c->ext, c->idx, c->n, c->Bs, c->PW, c->NW, wsplit
 #define CALL(KK)                                                                               \
-    hipLaunchKernelGGL(conv_pool_kernel<KK>, grid, dim3(64), sm, s, c->pk2, c->nmask,          \
-                       reinterpret_cast<const float4*>(c->lut), c->Wt, p->bn1_w, c->U, c->ext, c->idx, \
-                       c->n, c->Bs, c->PW, c->NW, wsplit)
+    if (cpw == 8) hipLaunchKernelGGL((conv_pool_kernel<KK, 8>), ARGS);                         \
+    else hipLaunchKernelGGL((conv_pool_kernel<KK, 32>), ARGS)
     K_DISPATCH(c->k, CALL);
 #undef CALL
+#undef ARGS
     LAUNCH_CHECK();
     return EXPLAINN_OK;
 }
 
 int conv_configure(explainn_ctx* c) {
-    const size_t sm = conv_pool_lds(c);
+    const int cpw = conv_pool_cpw(c);
+    const size_t sm = conv_pool_lds(c, cpw);
     if (sm > 48 * 1024) {
-#define CALL(KK)                                                                            \
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pool_kernel<KK>),   \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm))
+#define CALL(KK)                                                                               \
+        if (cpw == 8)                                                                          \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pool_kernel<KK, 8>), \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)); \
+        else                                                                                   \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pool_kernel<KK, 32>), \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm))
         K_DISPATCH(c->k, CALL);
 #undef CALL
     }
@@ -332,7 +377,7 @@ __global__ __launch_bounds__(256) void eval_fused_kernel(
     constexpr int NT = (K + 1) / 2;
     constexpr int CPW = 32;
     constexpr int PWC = ((POOLW * CPW + K + 15) >> 4) + 3, NWC = ((POOLW * CPW + K + 31) >> 5) + 2;
-    extern __shared__ __attribute__((aligned(16))) uint32_t esm[];
+    extern __shared__ __attribute__((aligned(256))) uint32_t esm[];
     float2* L2 = reinterpret_cast<float2*>(esm);                       // [NT][16]
     float2* Wp = L2 + NT * 16;                                         // [K][5]
     // code tiles, one per wave, sized for the windows a wave really has (n <= 40: at most 10):
@@ -395,7 +440,7 @@ __global__ __launch_bounds__(256) void eval_fused_kernel(
         const float al1 = alpha[min(u0 + 1, U - 1)], sf1 = shift[min(u0 + 1, U - 1)];
         __syncthreads();
         // ---- phase A: gather + pool + exp -> q tile ----
-        conv_pool_windows<K, 2>(L2, Wp, pks, nms, pk2, nmask, sg, b, lane, wbeg, wend, Bs, PW, NW,
+        conv_pool_windows<K, 2, CPW>(L2, Wp, pks, nms, pk2, nmask, sg, b, lane, wbeg, wend, Bs, PW, NW,
                                 [&](int w, const float (&e)[2], const int (&)[2]) {
                                     qs[w * EVAL_QLD + lane] = qval(al0, e[0], sf0);
                                     qs[(qrows + w) * EVAL_QLD + lane] = qval(al1, e[1], sf1);
