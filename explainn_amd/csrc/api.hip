@@ -57,6 +57,7 @@ void carve(explainn_ctx* c, Carver& cv) {
     cv.take(&c->VC, U * FC_H * NS);
     cv.take(&c->A2, U * FC_H * NS);
     cv.take(&c->A2f, U * FC_MT * fc_nk4q(c->NQ) * 256);
+    cv.take(&c->A2h, c->NQ <= FC_BF_MAXN ? U * FC_MT * fc_ks32(c->NQ) * 3 * 256 : 0);
     cv.take(&c->sh2, U * FC_H);
     cv.take(&c->sig2, U * FC_H);
     cv.take(&c->z, U * Bs);

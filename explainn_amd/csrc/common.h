@@ -63,6 +63,8 @@ struct explainn_ctx {
     float* VC;            // [U][100][NS]     V1 . C  (BN2 variance in prep2, BN2 backward in mid)
     float* A2;            // [U][100][NS]     FC1 weights with BN2 folded in
     float* A2f;           // [U][7][NK4Q][64][4] the same in MFMA 16x16x4 A-fragment order (fc_fwd stages it)
+    float* A2h;           // [U][7][KS][3][64][8] bf16: the same as three bf16 pieces in the A-fragment order of
+                          // v_mfma_f32_16x16x32_bf16 (fc_fwd for n <= FC_BF_MAXN; KS = 32-wide k-steps)
     float* sh2;           // [U][100]
     float* sig2;          // [U][100]
     float* z;             // [U][Bs]          FC2 output (without its bias)
@@ -305,6 +307,8 @@ static inline int nq_bucket(int n) {
 __host__ __device__ constexpr int fc_nk4(int NQ) { return (NQ + 3) / 4; }      // k-steps over pooled positions
 __host__ __device__ constexpr int fc_nk4q(int NQ) { return (fc_nk4(NQ) + 3) / 4; }  // ... in float4 groups of 4
 __host__ __device__ constexpr int fc_nw16(int NQ) { return (NQ + 15) / 16; }   // 16-wide tiles of pooled positions
+#define FC_BF_MAXN 96                                     // fc_fwd runs on the bf16 matrix core (exact 3x3 split) up to here
+__host__ __device__ constexpr int fc_ks32(int NQ) { return (NQ + 31) / 32; }   // 32-wide k-steps of the bf16 form
 // passA / passB split the w tiles into groups of WGT (one wave / workgroup per group)
 __host__ __device__ constexpr int fc_wgt(int NQ) { return fc_nw16(NQ) <= 2 ? fc_nw16(NQ) : 3; }
 __host__ __device__ constexpr int fc_ng(int NQ) { return (fc_nw16(NQ) + fc_wgt(NQ) - 1) / fc_wgt(NQ); }

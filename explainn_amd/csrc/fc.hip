@@ -39,6 +39,7 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
 
 #define FC_BTW 4                     // 16-sequence tiles per wavefront in fc_fwd
 #define PB_BTW 4                     // ... in passB
+#define FC_AHEAD 3                   // A-fragment reads in flight ahead of their MFMAs in the bf16 fc_fwd
 
 // MODE: 0 eval, 1 train without dropout, 2 train + counter-based generator, 3 train + keep-mask
 template <int NQ, int MODE>
@@ -182,9 +183,229 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(
     STAMP(4);
 }
 
+// ---------------------------------------------------------------------------------------------
+// fc_fwd on the bf16 matrix core (n <= FC_BF_MAXN).  Measured (profiles/r02): the fp32 MFMA and the
+// vector instructions of the epilogue do not overlap on a SIMD -- the kernel took the SUM of its
+// MFMA-busy and vector-issue times -- while a bf16 MFMA holds the vector issue for 8 of its 16
+// cycles.  Both operands are real here, so both are split exactly into three bf16 pieces
+// (x = hi + mid + lo with hi = top 16 bits of x, mid = top 16 bits of x - hi, lo = x - hi - mid: every
+// subtraction exact, 8+8+8 mantissa bits) and all nine piece products are accumulated: each is exact
+// in fp32 (8 x 8 bits), so D = sh2 + sum_w sum_pieces a_i q_j is an fp32 sum of exact products -- the
+// same function as the fmaf chain up to summation order -- at 9/16 of the fp32 MFMA's cycles and one
+// 32-wide k-step for the 26 pooled positions of the headline shape.
+//   A[row c][k = 8g + j] = A2 pieces (prep2's A2h image, staged in LDS), B[k = 8g + j][col c] = q pieces of
+//   sequence c built in registers; D layout as above, so the epilogue is the fp32 kernel's.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 fbf16x8;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int NQ, int MODE>
+__global__ __launch_bounds__(256, fc_ks32(NQ) == 1 ? 5 : 2) void fc_fwd_bf_kernel(
+    const float* __restrict__ ext, const float* __restrict__ alpha,
+    const float* __restrict__ shift, const uint32_t* __restrict__ A2h, const float* __restrict__ sh2,
+    const float* __restrict__ V2, uint4* __restrict__ bits, float* __restrict__ zout,
+    const uint8_t* __restrict__ keep_mask, uint32_t thresh16, float scale, uint32_t seed_lo,
+    uint32_t seed_hi, const float* __restrict__ c2, const float* __restrict__ g3,
+    const float* __restrict__ b3, const float* __restrict__ rm3, const float* __restrict__ rv3,
+    float* __restrict__ oout, int n, int Bs, int B, int U, const uint32_t* __restrict__ seed_dev) {
+    constexpr int KS = fc_ks32(NQ);
+    constexpr bool TRAIN = MODE != 0;
+    if (MODE == 2 && seed_dev) { seed_lo = seed_dev[0]; seed_hi = seed_dev[1]; }
+    extern __shared__ __attribute__((aligned(16))) float fsm[];
+    u32x4* Ah = reinterpret_cast<u32x4*>(fsm);               // [FC_MT][KS][3][64] x 8 bf16
+    float* sh2s = fsm + FC_MT * KS * 3 * 256;                // [112]
+    float* v2s = sh2s + FC_MT * 16;                          // [112]
+    const int u = blockIdx.y, bx = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const float* __restrict__ eu = ext + (size_t)u * n * Bs;
+    const int bt0 = (bx * 4 + wave) * FC_BTW;
+    STAMP(0);
+    // the first tile's raw pooled extremes are requested before the weight fragments are staged
+    float raw[KS][8];
+    {
+        const int b = min(bt0 * 16 + c, Bs - 1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) raw[ks][j] = eu[min(32 * ks + 8 * g + j, n - 1) * Bs + b];
+    }
+    {
+        const u32x4* src = reinterpret_cast<const u32x4*>(A2h) + (size_t)u * FC_MT * KS * 3 * 64;
+        constexpr int N4 = FC_MT * KS * 3 * 64;
+        u32x4 tv[(N4 + 255) / 256];
+#pragma unroll
+        for (int i = 0; i < (N4 + 255) / 256; ++i) tv[i] = src[min(tid + i * 256, N4 - 1)];
+#pragma unroll
+        for (int i = 0; i < (N4 + 255) / 256; ++i)
+            if (tid + i * 256 < N4) Ah[tid + i * 256] = tv[i];
+    }
+    if (tid < FC_MT * 16) {
+        sh2s[tid] = tid < FC_H ? sh2[(size_t)u * FC_H + tid] : 0.f;
+        v2s[tid] = tid < FC_H ? V2[(size_t)u * FC_H + tid] : 0.f;
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) KEEP(raw[ks][j]);
+    __syncthreads();
+    STAMP(1);
+    const float a1 = alpha[u], s1 = shift[u];
+    for (int it = 0; it < FC_BTW; ++it) {
+        const int bt = bt0 + it;
+        if (bt * 16 >= B) break;                       // wave-uniform
+        const int b = bt * 16 + c;
+        // q of this tile, split into its three bf16 pieces, two elements per word
+        u32x4 bq[KS][3];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int jp = 0; jp < 4; ++jp) {
+                float x[2], r1[2], r2[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    x[h] = (32 * ks + 8 * g + 2 * jp + h < n) ? qval(a1, raw[ks][2 * jp + h], s1) : 0.f;
+                    r1[h] = x[h] - __uint_as_float(__float_as_uint(x[h]) & 0xffff0000u);
+                    r2[h] = r1[h] - __uint_as_float(__float_as_uint(r1[h]) & 0xffff0000u);
+                }
+                // upper halves of the two values -> one word (element 2jp low, 2jp+1 high)
+                bq[ks][0][jp] = __builtin_amdgcn_perm(__float_as_uint(x[1]), __float_as_uint(x[0]), 0x07060302u);
+                bq[ks][1][jp] = __builtin_amdgcn_perm(__float_as_uint(r1[1]), __float_as_uint(r1[0]), 0x07060302u);
+                bq[ks][2][jp] = __builtin_amdgcn_perm(__float_as_uint(r2[1]), __float_as_uint(r2[0]), 0x07060302u);
+            }
+        }
+        if (it + 1 < FC_BTW && (bt + 1) * 16 < B) {    // next tile's loads fly under this tile's MFMAs
+            const int bn = min(b + 16, Bs - 1);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) raw[ks][j] = eu[min(32 * ks + 8 * g + j, n - 1) * Bs + bn];
+        }
+        uint32_t rs = 0;
+        if (MODE == 2)
+            rs = mix32(mix32(seed_lo ^ (uint32_t)(4 * b + g) * 0x9E3779B9U) ^
+                       mix32(seed_hi + (uint32_t)u)) | 1u;
+        const uint8_t* km = (MODE == 3) ? keep_mask + (size_t)min(b, B - 1) * FC_H * U + (size_t)u * FC_H
+                                        : nullptr;
+        if (it == 0) STAMP(2);
+        float zp = 0.f;
+        uint32_t words[4] = {0u, 0u, 0u, 0u};
+        f32x4 acc[FC_MT];
+#pragma unroll
+        for (int t = 0; t < FC_MT; ++t) {
+            const float4 v = *reinterpret_cast<const float4*>(&sh2s[16 * t + 4 * g]);
+            acc[t][0] = v.x; acc[t][1] = v.y; acc[t][2] = v.z; acc[t][3] = v.w;
+        }
+        // nine piece products per channel tile and k-step, smallest pieces first.  The A fragments
+        // come from LDS FC_AHEAD groups ahead of the three MFMAs that use them (a group = one
+        // fragment, three dependent MFMAs = 48 cycles; a ds_read_b128 takes ~130)
+        {
+            constexpr int NGRP = KS * 3 * FC_MT;
+            auto frag = [&](int i) -> u32x4 {
+                const int t = i % FC_MT, pa = 2 - (i / FC_MT) % 3, ks = i / (3 * FC_MT);
+                return Ah[((t * KS + ks) * 3 + pa) * 64 + lane];
+            };
+            u32x4 fr[FC_AHEAD + 1];
+#pragma unroll
+            for (int i = 0; i < FC_AHEAD; ++i) fr[i] = frag(i < NGRP ? i : NGRP - 1);
+#pragma unroll
+            for (int i = 0; i < NGRP; ++i) {
+                if (i + FC_AHEAD < NGRP) fr[(i + FC_AHEAD) % (FC_AHEAD + 1)] = frag(i + FC_AHEAD);
+                const int t = i % FC_MT, ks = i / (3 * FC_MT);
+                const fbf16x8 afr = __builtin_bit_cast(fbf16x8, fr[i % (FC_AHEAD + 1)]);
+#pragma unroll
+                for (int pb = 2; pb >= 0; --pb)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        afr, __builtin_bit_cast(fbf16x8, bq[ks][pb]), acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < FC_MT; ++t) {
+            const float4 v2 = *reinterpret_cast<const float4*>(&v2s[16 * t + 4 * g]);
+            const float v2a[4] = {v2.x, v2.y, v2.z, v2.w};
+            uint32_t nib = 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float y = acc[t][j];
+                bool pos = y > 0.f;
+                if (MODE == 2) {
+                    uint32_t rnd;
+                    if ((j & 1) == 0) { rs ^= rs << 13; rs ^= rs >> 17; rs ^= rs << 5; rnd = rs & 0xffffU; }
+                    else rnd = rs >> 16;
+                    pos = pos && (rnd >= thresh16);
+                } else if (MODE == 3) {
+                    const int r = 16 * t + 4 * g + j;
+                    pos = pos && (km[r < FC_H ? r : 0] != 0);
+                }
+                const float av = pos ? y * scale : 0.f;
+                zp = fmaf(v2a[j], av, zp);
+                nib |= (pos ? 1u : 0u) << j;
+            }
+            words[t >> 1] |= nib << (16 * (t & 1) + 4 * g);
+        }
+        if (it == 0) STAMP(3);
+        zp += __shfl_xor(zp, 16, 64);
+        zp += __shfl_xor(zp, 32, 64);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            words[k] |= __shfl_xor(words[k], 16, 64);
+            words[k] |= __shfl_xor(words[k], 32, 64);
+        }
+        if (g == 0 && b < Bs) {
+            if (TRAIN) {
+                zout[(size_t)u * Bs + b] = zp;
+                bits[(size_t)u * Bs + b] = make_uint4(words[0], words[1], words[2], words[3]);
+            } else {
+                const float inv = g3[u] / sqrtf(rv3[u] + (float)BN_EPS_D);
+                const float y3 = fmaf(inv, zp + c2[u] - rm3[u], b3[u]);
+                oout[(size_t)u * Bs + b] = fmaxf(y3, 0.f);
+            }
+        }
+    }
+    STAMP(4);
+}
+
+template <int NQ>
+static size_t fc_fwd_bf_lds() {
+    return (size_t)(FC_MT * fc_ks32(NQ) * 3 * 256 + 2 * FC_MT * 16) * sizeof(float);
+}
+
 template <int NQ>
 static size_t fc_fwd_lds() {
     return (size_t)(FC_MT * fc_nk4q(NQ) * 64 * 4 + 2 * FC_MT * 16) * sizeof(float);
+}
+
+// (templates, so that only the form a bucket uses is instantiated)
+template <int N, int MODE>
+static void fc_fwd_launch_nm(explainn_ctx* c, const explainn_params* p, int B, dim3 grid,
+                             const uint8_t* keep_mask, uint32_t thresh, float scale, uint64_t seed,
+                             hipStream_t s) {
+    const uint32_t* sd = c->capturing ? c->seed_dev : (const uint32_t*)nullptr;
+    if constexpr (N <= FC_BF_MAXN)
+        hipLaunchKernelGGL((fc_fwd_bf_kernel<N, MODE>), grid, dim3(256), fc_fwd_bf_lds<N>(), s, c->ext,
+                           c->alpha, c->shift, reinterpret_cast<const uint32_t*>(c->A2h), c->sh2,
+                           p->fc2_w, c->bits, c->z, keep_mask, thresh, scale, (uint32_t)seed,
+                           (uint32_t)(seed >> 32), p->fc2_b, p->bn3_w, p->bn3_b, p->bn3_rm, p->bn3_rv,
+                           c->o, c->n, c->Bs, B, c->U, sd);
+    else
+        hipLaunchKernelGGL((fc_fwd_kernel<N, MODE>), grid, dim3(256), fc_fwd_lds<N>(), s, c->ext,
+                           c->alpha, c->shift, c->A2f, c->sh2, p->fc2_w, c->bits, c->z, keep_mask,
+                           thresh, scale, (uint32_t)seed, (uint32_t)(seed >> 32), p->fc2_b, p->bn3_w,
+                           p->bn3_b, p->bn3_rm, p->bn3_rv, c->o, c->n, c->Bs, B, c->U, sd);
+}
+
+template <int N, int MODE>
+static int fc_fwd_configure_nm() {
+    if constexpr (N <= FC_BF_MAXN) {
+        if (fc_fwd_bf_lds<N>() > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_fwd_bf_kernel<N, MODE>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)fc_fwd_bf_lds<N>()));
+    } else {
+        if (fc_fwd_lds<N>() > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_fwd_kernel<N, MODE>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)fc_fwd_lds<N>()));
+    }
+    return EXPLAINN_OK;
 }
 
 int launch_fc_fwd(explainn_ctx* c, const explainn_params* p, int B, bool train,
@@ -200,20 +421,15 @@ int launch_fc_fwd(explainn_ctx* c, const explainn_params* p, int B, bool train,
         thresh = (uint32_t)(drop_p * 65536.0 + 0.5);
     }
     if (train) { c->fwd_drop = mode > 1; c->fwd_scale = scale; }
-#define ARGS c->ext, c->alpha, c->shift, c->A2f, c->sh2, p->fc2_w, c->bits, c->z, keep_mask, thresh, \
-             scale, (uint32_t)seed, (uint32_t)(seed >> 32), p->fc2_b, p->bn3_w, p->bn3_b,          \
-             p->bn3_rm, p->bn3_rv, c->o, c->n, c->Bs, B, c->U,                                   \
-             (c->capturing ? c->seed_dev : (const uint32_t*)nullptr)
 #define CALL(N)                                                                                    \
     switch (mode) {                                                                                \
-        case 0: hipLaunchKernelGGL((fc_fwd_kernel<N, 0>), grid, dim3(256), fc_fwd_lds<N>(), s, ARGS); break; \
-        case 1: hipLaunchKernelGGL((fc_fwd_kernel<N, 1>), grid, dim3(256), fc_fwd_lds<N>(), s, ARGS); break; \
-        case 2: hipLaunchKernelGGL((fc_fwd_kernel<N, 2>), grid, dim3(256), fc_fwd_lds<N>(), s, ARGS); break; \
-        default: hipLaunchKernelGGL((fc_fwd_kernel<N, 3>), grid, dim3(256), fc_fwd_lds<N>(), s, ARGS); break; \
+        case 0: fc_fwd_launch_nm<N, 0>(c, p, B, grid, keep_mask, thresh, scale, seed, s); break;   \
+        case 1: fc_fwd_launch_nm<N, 1>(c, p, B, grid, keep_mask, thresh, scale, seed, s); break;   \
+        case 2: fc_fwd_launch_nm<N, 2>(c, p, B, grid, keep_mask, thresh, scale, seed, s); break;   \
+        default: fc_fwd_launch_nm<N, 3>(c, p, B, grid, keep_mask, thresh, scale, seed, s); break;  \
     }
     NQ_DISPATCH(c->NQ, CALL);
 #undef CALL
-#undef ARGS
     LAUNCH_CHECK();
     return EXPLAINN_OK;
 }
@@ -560,16 +776,9 @@ int fc_configure(explainn_ctx* c) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&passB_kernel<N>),          \
                                     hipFuncAttributeMaxDynamicSharedMemorySize,              \
                                     (int)passB_lds<N>()));                                   \
-    if (fc_fwd_lds<N>() > 48 * 1024) {                                                       \
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_fwd_kernel<N, 0>),      \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)fc_fwd_lds<N>())); \
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_fwd_kernel<N, 1>),      \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)fc_fwd_lds<N>())); \
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_fwd_kernel<N, 2>),      \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)fc_fwd_lds<N>())); \
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_fwd_kernel<N, 3>),      \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)fc_fwd_lds<N>())); \
-    }
+    { int rc;                                                                                \
+      if ((rc = fc_fwd_configure_nm<N, 0>()) || (rc = fc_fwd_configure_nm<N, 1>()) ||        \
+          (rc = fc_fwd_configure_nm<N, 2>()) || (rc = fc_fwd_configure_nm<N, 3>())) return rc; }
     NQ_DISPATCH(c->NQ, CALL);
 #undef CALL
     return EXPLAINN_OK;

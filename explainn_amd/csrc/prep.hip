@@ -410,7 +410,8 @@ __global__ __launch_bounds__(1024) void prep2_kernel(
     float* __restrict__ rv2, int64_t* nbt, const float* __restrict__ qs0,
     const float* __restrict__ S1p, const float* __restrict__ S2p, double* __restrict__ qbar,
     float* __restrict__ VC, float* __restrict__ A2, float* __restrict__ A2f,
-    float* __restrict__ sh2, float* __restrict__ sig2, int n, int NS, int NK4Q, int B, int QCH) {
+    float* __restrict__ sh2, float* __restrict__ sig2, int n, int NS, int NK4Q, int B, int QCH,
+    uint32_t* __restrict__ A2h, int KS) {
     extern __shared__ double sm[];            // qb[NS] (double) | Cs[n][n] | V1s[100][n+1]
     const int u = blockIdx.x, tid = threadIdx.x;
     constexpr int NT = 1024;
@@ -568,31 +569,62 @@ __global__ __launch_bounds__(1024) void prep2_kernel(
         if (u == 0 && tid == 0 && nbt) *nbt += 1;
         STAMP(2);
     }
-    // the same weights in MFMA 16x16x4 A-fragment order for fc_fwd, four k-steps per float4:
-    // A2f[(((t*NK4Q + sq)*64 + l)*4 + e] = A2[16t + (l&15)][4*(4sq+e) + (l>>4)]
     __syncthreads();
     const float* a2lds = TRAIN ? reinterpret_cast<const float*>(sm + NS) + n * n : nullptr;   // = V1s
-    for (int i = tid; i < FC_MT * NK4Q * 256; i += NT) {
-        const int e = i & 3, l = (i >> 2) & 63, sq = (i >> 8) % NK4Q, t = (i >> 8) / NK4Q;
-        const int r = 16 * t + (l & 15), w = 4 * (4 * sq + e) + (l >> 4);
-        float v = 0.f;
-        if (r < FC_H && w < n) v = TRAIN ? a2lds[r * (n + 1) + w] : A2[((size_t)u * FC_H + r) * NS + w];
-        A2f[(size_t)u * FC_MT * NK4Q * 256 + i] = v;
+    if (A2h) {
+        // the same weights for fc_fwd's bf16 form: three bf16 pieces (hi + mid + lo = the weight,
+        // exactly) in the A-fragment order of v_mfma_f32_16x16x32_bf16, two elements per word:
+        // A2h[(((t*KS + ks)*3 + piece)*64 + l)*4 + jp] = pieces of A2[16t + (l&15)][32ks + 8(l>>4) + 2jp (+1)]
+        for (int i = tid; i < FC_MT * KS * 256; i += NT) {
+            const int jp = i & 3, l = (i >> 2) & 63, ks = (i >> 8) % KS, t = (i >> 8) / KS;
+            const int r = 16 * t + (l & 15), w = 32 * ks + 8 * (l >> 4) + 2 * jp;
+            uint32_t pc[3] = {0u, 0u, 0u};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float v = 0.f;
+                if (r < FC_H && w + h < n)
+                    v = TRAIN ? a2lds[r * (n + 1) + w + h] : A2[((size_t)u * FC_H + r) * NS + w + h];
+                const uint32_t hb = __float_as_uint(v) & 0xffff0000u;
+                const float r1 = v - __uint_as_float(hb);
+                const uint32_t mb = __float_as_uint(r1) & 0xffff0000u;
+                const float r2 = r1 - __uint_as_float(mb);
+                pc[0] |= (hb >> 16) << (16 * h);
+                pc[1] |= (mb >> 16) << (16 * h);
+                pc[2] |= (__float_as_uint(r2) >> 16) << (16 * h);
+            }
+            uint32_t* dst = A2h + ((size_t)(u * FC_MT + t) * KS + ks) * 3 * 256 + l * 4 + jp;
+            dst[0] = pc[0]; dst[256] = pc[1]; dst[512] = pc[2];
+        }
+    }
+    if (A2f) {
+        // ... and in MFMA 16x16x4 A-fragment order (large n, the single-launch eval), four k-steps per float4:
+        // A2f[(((t*NK4Q + sq)*64 + l)*4 + e] = A2[16t + (l&15)][4*(4sq+e) + (l>>4)]
+        for (int i = tid; i < FC_MT * NK4Q * 256; i += NT) {
+            const int e = i & 3, l = (i >> 2) & 63, sq = (i >> 8) % NK4Q, t = (i >> 8) / NK4Q;
+            const int r = 16 * t + (l & 15), w = 4 * (4 * sq + e) + (l >> 4);
+            float v = 0.f;
+            if (r < FC_H && w < n) v = TRAIN ? a2lds[r * (n + 1) + w] : A2[((size_t)u * FC_H + r) * NS + w];
+            A2f[(size_t)u * FC_MT * NK4Q * 256 + i] = v;
+        }
     }
     STAMP(3);
 }
 
 int launch_prep2(explainn_ctx* c, const explainn_params* p, int B, bool train, hipStream_t s) {
+    // fragment images of the folded weights: the bf16 pieces for fc_fwd where it runs on the bf16
+    // matrix core, the fp32 fragments for the large-n fc_fwd and for the (opt-in) single-launch eval
+    uint32_t* a2h = c->NQ <= FC_BF_MAXN ? reinterpret_cast<uint32_t*>(c->A2h) : nullptr;
+    float* a2f = (!a2h || !train) ? c->A2f : nullptr;   // (eval tables are cached: always complete)
     if (train)
         hipLaunchKernelGGL(prep2_kernel<true>, dim3(c->U), dim3(1024), prep2_lds(c->n, c->NS), s,
                            p->fc1_w, p->fc1_b, p->bn2_w, p->bn2_b, p->bn2_rm, p->bn2_rv, p->bn2_nbt,
-                           c->qs0, c->qS1p, c->qS2p, c->qbar, c->VC, c->A2, c->A2f, c->sh2, c->sig2,
-                           c->n, c->NS, fc_nk4q(c->NQ), B, c->QCH);
+                           c->qs0, c->qS1p, c->qS2p, c->qbar, c->VC, c->A2, a2f, c->sh2, c->sig2,
+                           c->n, c->NS, fc_nk4q(c->NQ), B, c->QCH, a2h, fc_ks32(c->NQ));
     else
         hipLaunchKernelGGL(prep2_kernel<false>, dim3(c->U), dim3(1024), 0, s, p->fc1_w, p->fc1_b,
                            p->bn2_w, p->bn2_b, p->bn2_rm, p->bn2_rv, (int64_t*)nullptr, c->qs0,
-                           c->qS1p, c->qS2p, c->qbar, c->VC, c->A2, c->A2f, c->sh2, c->sig2, c->n,
-                           c->NS, fc_nk4q(c->NQ), B, c->QCH);
+                           c->qS1p, c->qS2p, c->qbar, c->VC, c->A2, a2f, c->sh2, c->sig2, c->n,
+                           c->NS, fc_nk4q(c->NQ), B, c->QCH, a2h, fc_ks32(c->NQ));
     LAUNCH_CHECK();
     return EXPLAINN_OK;
 }

@@ -713,9 +713,10 @@ def test_eval_tables_follow_parameter_changes():
 def test_single_launch_eval_kernel(monkeypatch):
     """EXPLAINN_EVAL_FUSED=1: the eval forward as pack + ONE launch (filter bank -> pooling -> exp
     -> FC -> combiner with the pooled activations in LDS, partial logits combined by the last
-    workgroup of each sequence tile).  Same numbers as the default path (bit for bit in the unit
-    outputs; logits to rounding: the combiner sums units in another order) and as the golden
-    vectors; deterministic from call to call."""
+    workgroup of each sequence tile).  Same numbers as the default path to rounding (its FC runs on
+    the fp32 matrix core, the default one as nine exact bf16 piece products: another summation
+    order; the combiner sums units in another order) and as the golden vectors; deterministic from
+    call to call."""
     for name in ("small_u8_k19", "mid_u8_k19_L200", "tiny_u3_k5_N", "c1_u100_k19_L200"):
         g = Golden(name)
         m = _model(g.sd(), g.U, g.k, g.L, g.T).eval()
@@ -727,7 +728,7 @@ def test_single_launch_eval_kernel(monkeypatch):
             a, b = m(x), m(x)
             outs = m.linears(x.repeat(1, g.U, 1))
         assert torch.equal(a, b), name
-        assert torch.equal(outs, ref_outs), name
+        _close(_np(outs), _np(ref_outs), tol=2e-6, what=name + " fused vs default unit outputs")
         _close(_np(a), _np(ref_logits), tol=2e-6, what=name + " fused vs default logits")
         _close(_np(a), g.z["eval/logits"], what=name + " fused eval logits")
     monkeypatch.delenv("EXPLAINN_EVAL_FUSED", raising=False)
