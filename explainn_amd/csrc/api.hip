@@ -64,6 +64,8 @@ void carve(explainn_ctx* c, Carver& cv) {
     cv.take(&c->zhat, U * Bs);
     cv.take(&c->o, U * Bs);
     cv.take(&c->sig3, U);
+    c->ZBLK = fc_fwd_blocks((int)Bs);
+    cv.take(&c->z12p, U * c->ZBLK * 2);
     cv.take(&c->bits, U * Bs + 4);
     cv.take(&c->dz, U * Bs + 4);
     cv.take(&c->EQp, U * c->ACH * FC_H * NS);

@@ -71,6 +71,8 @@ struct explainn_ctx {
     float* zhat;          // [U][Bs]
     float* o;             // [U][Bs]          unit outputs
     float* sig3;          // [U]
+    double* z12p;         // [U][ZBLK][2] per-workgroup fp64 sums of z and z^2 from fc_fwd (train)
+    int ZBLK;             // fc_fwd workgroups per unit at the largest batch
     uint4* bits;          // [U][Bs]          100 bits per (unit, sequence): relu'>0 and kept
     float* dz;            // [U][Bs]
     float* EQp;           // [U][ACH][NS][100]  passA's partial sums, w-major (four rows r = one 16-byte store)
@@ -307,6 +309,9 @@ static inline int nq_bucket(int n) {
 __host__ __device__ constexpr int fc_nk4(int NQ) { return (NQ + 3) / 4; }      // k-steps over pooled positions
 __host__ __device__ constexpr int fc_nk4q(int NQ) { return (fc_nk4(NQ) + 3) / 4; }  // ... in float4 groups of 4
 __host__ __device__ constexpr int fc_nw16(int NQ) { return (NQ + 15) / 16; }   // 16-wide tiles of pooled positions
+// workgroups per unit of an fc_fwd launch (fc.hip: 4 waves x FC_BTW tiles of 16 sequences)
+#define FC_BTW 4
+__host__ __device__ constexpr int fc_fwd_blocks(int B) { return ((B + 15) / 16 + 4 * FC_BTW - 1) / (4 * FC_BTW); }
 #define FC_BF_MAXN 96                                     // fc_fwd runs on the bf16 matrix core (exact 3x3 split) up to here
 __host__ __device__ constexpr int fc_ks32(int NQ) { return (NQ + 31) / 32; }   // 32-wide k-steps of the bf16 form
 // passA / passB split the w tiles into groups of WGT (one wave / workgroup per group)

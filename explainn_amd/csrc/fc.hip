@@ -37,7 +37,57 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     return x;
 }
 
-#define FC_BTW 4                     // 16-sequence tiles per wavefront in fc_fwd
+// Lane-local epilogue of one 16-channel tile: the lane holds channels r = 16t + 4g + j (j = 0..3) of ITS
+// sequence.  ReLU, dropout (MODE 2: counter-based generator, two 16-bit draws per xorshift step;
+// MODE 3: the caller's keep mask), the FC2 partial dot product (v2s = V2 * 1/(1-p): the dropout scale
+// is folded into the weights when they are staged) and the "relu' > 0 and kept" bits.
+template <int MODE>
+__device__ __forceinline__ void fc_epilogue_tile(const f32x4& acc, int t, int g, const float* v2s,
+                                                 uint32_t& rs, uint32_t thresh16, const uint8_t* km,
+                                                 float& zp, uint32_t (&words)[4]) {
+    const float4 v2 = *reinterpret_cast<const float4*>(&v2s[16 * t + 4 * g]);
+    const float v2a[4] = {v2.x, v2.y, v2.z, v2.w};
+    bool pos[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float y = acc[j];
+        pos[j] = y > 0.f;
+        if (MODE == 2) {
+            uint32_t rnd;
+            if ((j & 1) == 0) { rs ^= rs << 13; rs ^= rs >> 17; rs ^= rs << 5; rnd = rs & 0xffffU; }
+            else rnd = rs >> 16;
+            pos[j] = pos[j] && (rnd >= thresh16);
+        } else if (MODE == 3) {
+            const int r = 16 * t + 4 * g + j;
+            pos[j] = pos[j] && (km[r < FC_H ? r : 0] != 0);
+        }
+        zp = fmaf(v2a[j], pos[j] ? y : 0.f, zp);
+    }
+    // bit j of the nibble = pos[j]: shift-and-add-carry, one instruction per channel
+    uint32_t nib = 0u;
+#pragma unroll
+    for (int j = 3; j >= 0; --j) nib = nib + nib + (pos[j] ? 1u : 0u);
+    // channel r = 16t + 4g + j is bit (r & 31) of word r >> 5
+    words[t >> 1] |= nib << (16 * (t & 1) + 4 * g);
+}
+
+// Workgroup total of the z moments (fixed order: lanes by butterfly, waves 0..3) -> z12p[u][bx]
+__device__ __forceinline__ void fc_zmom_finish(double s1, double s2, double* __restrict__ z12p, int u,
+                                               int bx, int nbx, int wave, int lane) {
+    __shared__ double zred[4][2];
+    // only lanes 0..15 (g = 0) hold sums: four butterfly steps bring their total to lane 0
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+    if (lane == 0) { zred[wave][0] = s1; zred[wave][1] = s2; }
+    __syncthreads();
+    if (wave == 0 && lane == 0) {
+        double* dst = z12p + ((size_t)u * nbx + bx) * 2;
+        dst[0] = (zred[0][0] + zred[1][0]) + (zred[2][0] + zred[3][0]);
+        dst[1] = (zred[0][1] + zred[1][1]) + (zred[2][1] + zred[3][1]);
+    }
+}
+
+// FC_BTW (common.h): 16-sequence tiles per wavefront in fc_fwd
 #define PB_BTW 4                     // ... in passB
 #define FC_AHEAD 3                   // A-fragment reads in flight ahead of their MFMAs in the bf16 fc_fwd
 
@@ -50,7 +100,8 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(
     const uint8_t* __restrict__ keep_mask, uint32_t thresh16, float scale, uint32_t seed_lo,
     uint32_t seed_hi, const float* __restrict__ c2, const float* __restrict__ g3,
     const float* __restrict__ b3, const float* __restrict__ rm3, const float* __restrict__ rv3,
-    float* __restrict__ oout, int n, int Bs, int B, int U, const uint32_t* __restrict__ seed_dev) {
+    float* __restrict__ oout, int n, int Bs, int B, int U, const uint32_t* __restrict__ seed_dev,
+    double* __restrict__ z12p) {
     constexpr int NK4 = fc_nk4(NQ), NK4Q = fc_nk4q(NQ);
     constexpr bool TRAIN = MODE != 0;
     // a captured step (hipGraph) reads its dropout seed from device memory, so that replays can
@@ -88,13 +139,17 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(
     }
     if (tid < FC_MT * 16) {
         sh2s[tid] = tid < FC_H ? sh2[(size_t)u * FC_H + tid] : 0.f;
-        v2s[tid] = tid < FC_H ? V2[(size_t)u * FC_H + tid] : 0.f;
+        v2s[tid] = tid < FC_H ? V2[(size_t)u * FC_H + tid] * scale : 0.f;
     }
 #pragma unroll
     for (int s = 0; s < NK4; ++s) KEEP(raw[s]);
     __syncthreads();
     STAMP(1);
     const float a1 = alpha[u], s1 = shift[u];
+    // train: sums of z and z^2 over this workgroup's sequences for BatchNorm3's batch statistics
+    // (head.hip finishes them inside the combiner launch); fp64, unshifted: a shift would have to be
+    // state (the running mean) and make the step's rounding depend on it
+    double zs1 = 0, zs2 = 0;
     for (int it = 0; it < FC_BTW; ++it) {
         const int bt = bt0 + it;
         if (bt * 16 >= B) break;                       // wave-uniform
@@ -136,30 +191,8 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(
             }
         }
 #pragma unroll
-        for (int t = 0; t < FC_MT; ++t) {
-            const float4 v2 = *reinterpret_cast<const float4*>(&v2s[16 * t + 4 * g]);
-            const float v2a[4] = {v2.x, v2.y, v2.z, v2.w};
-            uint32_t nib = 0u;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float y = acc[t][j];
-                bool pos = y > 0.f;
-                if (MODE == 2) {
-                    uint32_t rnd;
-                    if ((j & 1) == 0) { rs ^= rs << 13; rs ^= rs >> 17; rs ^= rs << 5; rnd = rs & 0xffffU; }
-                    else rnd = rs >> 16;
-                    pos = pos && (rnd >= thresh16);
-                } else if (MODE == 3) {
-                    const int r = 16 * t + 4 * g + j;
-                    pos = pos && (km[r < FC_H ? r : 0] != 0);
-                }
-                const float av = pos ? y * scale : 0.f;
-                zp = fmaf(v2a[j], av, zp);
-                nib |= (pos ? 1u : 0u) << j;
-            }
-            // channel r = 16t + 4g + j is bit (r & 31) of word r >> 5
-            words[t >> 1] |= nib << (16 * (t & 1) + 4 * g);
-        }
+        for (int t = 0; t < FC_MT; ++t)
+            fc_epilogue_tile<MODE>(acc[t], t, g, v2s, rs, thresh16, km, zp, words);
         if (it == 0) STAMP(3);
         // the four lane groups of a sequence hold disjoint channel sets: merge across g
         zp += __shfl_xor(zp, 16, 64);
@@ -169,6 +202,7 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(
             words[k] |= __shfl_xor(words[k], 16, 64);
             words[k] |= __shfl_xor(words[k], 32, 64);
         }
+        if (TRAIN && g == 0 && b < B) { const double d = (double)zp; zs1 += d; zs2 = fma(d, d, zs2); }
         if (g == 0 && b < Bs) {
             if (TRAIN) {
                 zout[(size_t)u * Bs + b] = zp;
@@ -180,6 +214,7 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(
             }
         }
     }
+    if (TRAIN) fc_zmom_finish(zs1, zs2, z12p, u, bx, gridDim.x, wave, lane);
     STAMP(4);
 }
 
@@ -207,7 +242,8 @@ __global__ __launch_bounds__(256, fc_ks32(NQ) == 1 ? 5 : 2) void fc_fwd_bf_kerne
     const uint8_t* __restrict__ keep_mask, uint32_t thresh16, float scale, uint32_t seed_lo,
     uint32_t seed_hi, const float* __restrict__ c2, const float* __restrict__ g3,
     const float* __restrict__ b3, const float* __restrict__ rm3, const float* __restrict__ rv3,
-    float* __restrict__ oout, int n, int Bs, int B, int U, const uint32_t* __restrict__ seed_dev) {
+    float* __restrict__ oout, int n, int Bs, int B, int U, const uint32_t* __restrict__ seed_dev,
+    double* __restrict__ z12p) {
     constexpr int KS = fc_ks32(NQ);
     constexpr bool TRAIN = MODE != 0;
     if (MODE == 2 && seed_dev) { seed_lo = seed_dev[0]; seed_hi = seed_dev[1]; }
@@ -241,7 +277,7 @@ __global__ __launch_bounds__(256, fc_ks32(NQ) == 1 ? 5 : 2) void fc_fwd_bf_kerne
     }
     if (tid < FC_MT * 16) {
         sh2s[tid] = tid < FC_H ? sh2[(size_t)u * FC_H + tid] : 0.f;
-        v2s[tid] = tid < FC_H ? V2[(size_t)u * FC_H + tid] : 0.f;
+        v2s[tid] = tid < FC_H ? V2[(size_t)u * FC_H + tid] * scale : 0.f;
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
@@ -250,6 +286,10 @@ __global__ __launch_bounds__(256, fc_ks32(NQ) == 1 ? 5 : 2) void fc_fwd_bf_kerne
     __syncthreads();
     STAMP(1);
     const float a1 = alpha[u], s1 = shift[u];
+    // train: sums of z and z^2 over this workgroup's sequences for BatchNorm3's batch statistics
+    // (head.hip finishes them inside the combiner launch); fp64, unshifted: a shift would have to be
+    // state (the running mean) and make the step's rounding depend on it
+    double zs1 = 0, zs2 = 0;
     for (int it = 0; it < FC_BTW; ++it) {
         const int bt = bt0 + it;
         if (bt * 16 >= B) break;                       // wave-uniform
@@ -320,29 +360,8 @@ __global__ __launch_bounds__(256, fc_ks32(NQ) == 1 ? 5 : 2) void fc_fwd_bf_kerne
             }
         }
 #pragma unroll
-        for (int t = 0; t < FC_MT; ++t) {
-            const float4 v2 = *reinterpret_cast<const float4*>(&v2s[16 * t + 4 * g]);
-            const float v2a[4] = {v2.x, v2.y, v2.z, v2.w};
-            uint32_t nib = 0u;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float y = acc[t][j];
-                bool pos = y > 0.f;
-                if (MODE == 2) {
-                    uint32_t rnd;
-                    if ((j & 1) == 0) { rs ^= rs << 13; rs ^= rs >> 17; rs ^= rs << 5; rnd = rs & 0xffffU; }
-                    else rnd = rs >> 16;
-                    pos = pos && (rnd >= thresh16);
-                } else if (MODE == 3) {
-                    const int r = 16 * t + 4 * g + j;
-                    pos = pos && (km[r < FC_H ? r : 0] != 0);
-                }
-                const float av = pos ? y * scale : 0.f;
-                zp = fmaf(v2a[j], av, zp);
-                nib |= (pos ? 1u : 0u) << j;
-            }
-            words[t >> 1] |= nib << (16 * (t & 1) + 4 * g);
-        }
+        for (int t = 0; t < FC_MT; ++t)
+            fc_epilogue_tile<MODE>(acc[t], t, g, v2s, rs, thresh16, km, zp, words);
         if (it == 0) STAMP(3);
         zp += __shfl_xor(zp, 16, 64);
         zp += __shfl_xor(zp, 32, 64);
@@ -351,6 +370,7 @@ __global__ __launch_bounds__(256, fc_ks32(NQ) == 1 ? 5 : 2) void fc_fwd_bf_kerne
             words[k] |= __shfl_xor(words[k], 16, 64);
             words[k] |= __shfl_xor(words[k], 32, 64);
         }
+        if (TRAIN && g == 0 && b < B) { const double d = (double)zp; zs1 += d; zs2 = fma(d, d, zs2); }
         if (g == 0 && b < Bs) {
             if (TRAIN) {
                 zout[(size_t)u * Bs + b] = zp;
@@ -362,6 +382,7 @@ __global__ __launch_bounds__(256, fc_ks32(NQ) == 1 ? 5 : 2) void fc_fwd_bf_kerne
             }
         }
     }
+    if (TRAIN) fc_zmom_finish(zs1, zs2, z12p, u, bx, gridDim.x, wave, lane);
     STAMP(4);
 }
 
@@ -386,12 +407,12 @@ static void fc_fwd_launch_nm(explainn_ctx* c, const explainn_params* p, int B, d
                            c->alpha, c->shift, reinterpret_cast<const uint32_t*>(c->A2h), c->sh2,
                            p->fc2_w, c->bits, c->z, keep_mask, thresh, scale, (uint32_t)seed,
                            (uint32_t)(seed >> 32), p->fc2_b, p->bn3_w, p->bn3_b, p->bn3_rm, p->bn3_rv,
-                           c->o, c->n, c->Bs, B, c->U, sd);
+                           c->o, c->n, c->Bs, B, c->U, sd, c->z12p);
     else
         hipLaunchKernelGGL((fc_fwd_kernel<N, MODE>), grid, dim3(256), fc_fwd_lds<N>(), s, c->ext,
                            c->alpha, c->shift, c->A2f, c->sh2, p->fc2_w, c->bits, c->z, keep_mask,
                            thresh, scale, (uint32_t)seed, (uint32_t)(seed >> 32), p->fc2_b, p->bn3_w,
-                           p->bn3_b, p->bn3_rm, p->bn3_rv, c->o, c->n, c->Bs, B, c->U, sd);
+                           p->bn3_b, p->bn3_rm, p->bn3_rv, c->o, c->n, c->Bs, B, c->U, sd, c->z12p);
 }
 
 template <int N, int MODE>
@@ -411,7 +432,7 @@ static int fc_fwd_configure_nm() {
 int launch_fc_fwd(explainn_ctx* c, const explainn_params* p, int B, bool train,
                   const uint8_t* keep_mask, float drop_p, uint64_t seed, hipStream_t s) {
     const int tiles = (B + 15) / 16;
-    const dim3 grid((tiles + 4 * FC_BTW - 1) / (4 * FC_BTW), c->U);
+    const dim3 grid(fc_fwd_blocks(B), c->U);
     int mode = train ? 1 : 0;
     float scale = 1.f;
     uint32_t thresh = 0;
@@ -462,7 +483,7 @@ __host__ __device__ constexpr int pa_wgt(int NQ) { return pa_nw16(NQ) <= 2 ? pa_
 __host__ __device__ constexpr int pa_ng(int NQ) { return (pa_nw16(NQ) + pa_wgt(NQ) - 1) / pa_wgt(NQ); }
 
 template <int NQ>
-__global__ __launch_bounds__(64) void passA_kernel(const float* __restrict__ ext,
+__global__ __launch_bounds__(64, 3) void passA_kernel(const float* __restrict__ ext,
                                                    const float* __restrict__ alpha,
                                                    const float* __restrict__ shift,
                                                    const float* __restrict__ dz,

@@ -197,6 +197,75 @@ __global__ __launch_bounds__(1024) void logits_kernel(const float* __restrict__ 
     }
 }
 
+// Train forward, few tasks: BatchNorm3's batch statistics are FINISHED here, inside the combiner
+// launch, from the per-workgroup fp64 sums of z and z^2 fc_fwd left in z12p -- head_fwd_train's
+// launch (~5 us for 300 x 1024 values) disappears.  Every block rebuilds the statistics of all units
+// (U x NBLK pairs of doubles, a few KB from L2), normalises its 64 sequences on the fly and sums the
+// combiner; the blocks of task 0 also store zhat and o for the backward, block (0, 0) the running
+// statistics.  Same grid and summation order as logits_kernel.
+__global__ __launch_bounds__(1024) void logits_bn_kernel(
+    const float* __restrict__ z, const double* __restrict__ z12p, int nblk, const float* __restrict__ c2, const float* __restrict__ g3, const float* __restrict__ b3,
+    float* __restrict__ rm3, float* __restrict__ rv3, int64_t* nbt, float* __restrict__ zhat,
+    float* __restrict__ o, float* __restrict__ sig3, const float* __restrict__ Wf,
+    const float* __restrict__ bf, float* __restrict__ logits, int U, int T, int Bs, int B) {
+    extern __shared__ float4 st4[];                   // [U] {mean, 1/sigma, gamma, beta}
+    __shared__ float part[16][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.x * 64 + lane, t = blockIdx.y;
+    const bool owner = blockIdx.x == 0 && blockIdx.y == 0;
+    for (int u = threadIdx.x; u < U; u += 1024) {
+        double s1 = 0, s2 = 0;
+        for (int i = 0; i < nblk; ++i) {
+            s1 += z12p[((size_t)u * nblk + i) * 2];
+            s2 += z12p[((size_t)u * nblk + i) * 2 + 1];
+        }
+        const double mean = s1 / (double)B;
+        const double var = fmax(s2 / (double)B - mean * mean, 0.0);
+        const double sg = sqrt(var + BN_EPS_D);
+        st4[u] = make_float4((float)mean, (float)(1.0 / sg), g3[u], b3[u]);
+        if (owner) {
+            sig3[u] = (float)sg;
+            rm3[u] = (float)((1 - BN_MOM_D) * (double)rm3[u] + BN_MOM_D * (mean + (double)c2[u]));
+            rv3[u] = (float)((1 - BN_MOM_D) * (double)rv3[u] + BN_MOM_D * var * (double)B / (double)(B - 1));
+            if (u == 0 && nbt) *nbt += 1;
+        }
+    }
+    __syncthreads();
+    const float* wr = Wf + (size_t)t * U;
+    const bool store = t == 0 && b < B;
+    float acc = 0.f;
+    for (int u0 = wv; u0 < U; u0 += 160) {             // ten units (twenty loads) in flight
+        float wq[10], zq[10];
+#pragma unroll
+        for (int q = 0; q < 10; ++q) {
+            const int u = min(u0 + 16 * q, U - 1);
+            wq[q] = wr[u];
+            zq[q] = z[(size_t)u * Bs + b];
+        }
+#pragma unroll
+        for (int q = 0; q < 10; ++q) { KEEP(wq[q]); KEEP(zq[q]); }
+#pragma unroll
+        for (int q = 0; q < 10; ++q) {
+            const int u = u0 + 16 * q;
+            if (u < U) {                               // wave-uniform
+                const float4 sv = st4[u];
+                const float zh = (zq[q] - sv.x) * sv.y;
+                const float ov = fmaxf(fmaf(sv.z, zh, sv.w), 0.f);
+                if (store) { zhat[(size_t)u * Bs + b] = zh; o[(size_t)u * Bs + b] = ov; }
+                acc = fmaf(wq[q], ov, acc);
+            }
+        }
+    }
+    part[wv][lane] = acc;
+    __syncthreads();
+    if (wv == 0 && b < B) {
+        float s = bf[t];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += part[i][lane];
+        logits[(size_t)b * T + t] = s;
+    }
+}
+
 // outs[b][u] = o[u][b]   (model.linears(x) output layout, test.py:151)
 __global__ __launch_bounds__(256) void outs_kernel(const float* __restrict__ o,
                                                    float* __restrict__ outs, int U, int Bs, int B) {
@@ -208,6 +277,14 @@ __global__ __launch_bounds__(256) void outs_kernel(const float* __restrict__ o,
 
 int launch_head_fwd(explainn_ctx* c, const explainn_params* p, int B, bool train, float* logits,
                     float* outs, hipStream_t s) {
+    if (train && logits && c->T <= HEAD_GEMM_MIN_T && !outs && (size_t)c->U * sizeof(float4) <= 48 * 1024) {
+        hipLaunchKernelGGL(logits_bn_kernel, dim3((B + 63) / 64, c->T), dim3(1024),
+                           (size_t)c->U * sizeof(float4), s, c->z, c->z12p, fc_fwd_blocks(B),
+                           p->fc2_b, p->bn3_w, p->bn3_b, p->bn3_rm, p->bn3_rv, p->bn3_nbt, c->zhat,
+                           c->o, c->sig3, p->final_w, p->final_b, logits, c->U, c->T, c->Bs, B);
+        LAUNCH_CHECK();
+        return EXPLAINN_OK;
+    }
     if (train) {
         hipLaunchKernelGGL(head_fwd_train_kernel, dim3(c->U), dim3(256), 0, s, c->z, p->fc2_b,
                            p->bn3_w, p->bn3_b, p->bn3_rm, p->bn3_rv, p->bn3_nbt, c->zhat, c->o,
