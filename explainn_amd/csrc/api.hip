@@ -64,7 +64,7 @@ void carve(explainn_ctx* c, Carver& cv) {
     cv.take(&c->zhat, U * Bs);
     cv.take(&c->o, U * Bs);
     cv.take(&c->sig3, U);
-    c->ZBLK = fc_fwd_blocks((int)Bs);
+    c->ZBLK = fc_fwd_blocks((int)Bs, c->NQ);
     cv.take(&c->z12p, U * c->ZBLK * 2);
     cv.take(&c->bits, U * Bs + 4);
     cv.take(&c->dz, U * Bs + 4);
@@ -387,8 +387,8 @@ namespace {
 // after backward_fc every gradient from fc1_w to final_b (the tail of explainn_grads) is final;
 // backward_conv then produces conv_w, conv_b, bn1_w, bn1_b
 int backward_fc(explainn_ctx* c, int B, const explainn_params* p, const explainn_grads* g,
-                hipStream_t s) {
-    STAGE(ST_PASSA, launch_passA(c, B, s));
+                const pa_head_args* head, hipStream_t s) {
+    STAGE(ST_PASSA, launch_passA(c, B, head, s));
     STAGE(ST_MID, launch_mid_bwd(c, p, g, B, s));
     return EXPLAINN_OK;
 }
@@ -402,9 +402,24 @@ int backward_conv(explainn_ctx* c, int B, const explainn_params* p, const explai
     return EXPLAINN_OK;
 }
 
+// Few tasks and a small batch: the head backward runs inside passA (fc.hip; mode 1 = dlogits given,
+// 2 = from the loss).  Every passA wave then makes the full-batch pass of BatchNorm3's backward
+// itself: worth a launch (~5 us) up to a few hundred sequences -- 0.120 -> 0.115 ms per step at 100
+// units x 64 sequences -- and a wash at 1024 (passA +9.6 us, head_bwd -9.6 us; MI355X), so larger
+// batches keep the per-unit kernel.
+bool head_rides_in_passA(const explainn_ctx* c, int B) { return c->T <= PA_HEAD_MAX_T && B <= 512; }
+
+pa_head_args head_in_passA(explainn_ctx* c, const explainn_params* p, const explainn_grads* g, int mode,
+                           const float* dl, int kind, const float* logits, const float* y,
+                           float* loss_out) {
+    pa_head_args h = {mode, c->T, kind, dl, logits, y, loss_out, p->final_w, p->bn3_w, c->o, c->zhat,
+                      c->sig3, c->dz, g->final_w, g->final_b, g->bn3_w, g->bn3_b, g->fc2_b};
+    return h;
+}
+
 int backward_tail(explainn_ctx* c, int B, const explainn_params* p, const explainn_grads* g,
-                  int freeze_top_n_filters, hipStream_t s) {
-    TRY(backward_fc(c, B, p, g, s));
+                  int freeze_top_n_filters, const pa_head_args* head, hipStream_t s) {
+    TRY(backward_fc(c, B, p, g, head, s));
     return backward_conv(c, B, p, g, freeze_top_n_filters, s);
 }
 }  // namespace
@@ -419,8 +434,12 @@ extern "C" int explainn_backward(explainn_ctx* c, const float* dlogits, int B,
         return EXPLAINN_E_STATE;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (head_rides_in_passA(c, B)) {
+        const pa_head_args h = head_in_passA(c, p, g, 1, dlogits, 0, nullptr, nullptr, nullptr);
+        return backward_tail(c, B, p, g, freeze_top_n_filters, &h, s);
+    }
     STAGE(ST_HEAD_BWD, launch_head_bwd(c, p, g, dlogits, B, s));
-    return backward_tail(c, B, p, g, freeze_top_n_filters, s);
+    return backward_tail(c, B, p, g, freeze_top_n_filters, nullptr, s);
 }
 
 extern "C" int explainn_loss_grad(explainn_ctx* c, int loss_kind, const float* logits,
@@ -446,6 +465,11 @@ int train_step_front(explainn_ctx* c, const float* x, const float* targets, int 
     if (c) c->tail_B = 0;
     TRY(explainn_forward_train(c, x, B, p, nullptr, dropout_p, seed, logits, stream));
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (head_rides_in_passA(c, B)) {
+        // few tasks, small batch: loss, loss gradient and head backward all ride in passA's prologue
+        const pa_head_args h = head_in_passA(c, p, g, 2, nullptr, loss_kind, logits, targets, loss_out);
+        return backward_fc(c, B, p, g, &h, s);
+    }
     if (c->T <= 4) {
         // few tasks: the loss gradient is recomputed inside the head backward (one launch less)
         STAGE(ST_HEAD_BWD, launch_head_bwd_fused_loss(c, p, g, loss_kind, logits, targets, loss_out, B, s));
@@ -453,7 +477,7 @@ int train_step_front(explainn_ctx* c, const float* x, const float* targets, int 
         STAGE(ST_LOSS, explainn_loss_grad(c, loss_kind, logits, targets, B, loss_out, c->dlogits, stream));
         STAGE(ST_HEAD_BWD, launch_head_bwd(c, p, g, c->dlogits, B, s));
     }
-    return backward_fc(c, B, p, g, s);
+    return backward_fc(c, B, p, g, nullptr, s);
 }
 }  // namespace
 

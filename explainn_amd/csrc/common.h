@@ -156,7 +156,17 @@ int launch_head_bwd(explainn_ctx* c, const explainn_params* p, const explainn_gr
 int launch_head_bwd_fused_loss(explainn_ctx* c, const explainn_params* p, const explainn_grads* g,
                                int kind, const float* logits, const float* y, float* loss_out, int B,
                                hipStream_t s);
-int launch_passA(explainn_ctx* c, int B, hipStream_t s);
+// The head backward of a few-task model (T <= PA_HEAD_MAX_T) rides in passA's prologue (fc.hip):
+// mode 1 = d loss / d logits given (dl), mode 2 = recomputed from logits and targets (+ the loss value)
+#define PA_HEAD_MAX_T 4
+struct pa_head_args {
+    int mode, T, kind;
+    const float *dl, *logits, *y;
+    float* loss_out;
+    const float *Wf, *g3, *o, *zhat, *sig3;
+    float *dz, *gWf, *gbf, *gg3, *gb3, *gc2;
+};
+int launch_passA(explainn_ctx* c, int B, const pa_head_args* head, hipStream_t s);
 int launch_mid_bwd(explainn_ctx* c, const explainn_params* p, const explainn_grads* g, int B,
                    hipStream_t s);
 int launch_passB(explainn_ctx* c, int B, hipStream_t s);
@@ -309,9 +319,18 @@ static inline int nq_bucket(int n) {
 __host__ __device__ constexpr int fc_nk4(int NQ) { return (NQ + 3) / 4; }      // k-steps over pooled positions
 __host__ __device__ constexpr int fc_nk4q(int NQ) { return (fc_nk4(NQ) + 3) / 4; }  // ... in float4 groups of 4
 __host__ __device__ constexpr int fc_nw16(int NQ) { return (NQ + 15) / 16; }   // 16-wide tiles of pooled positions
-// workgroups per unit of an fc_fwd launch (fc.hip: 4 waves x FC_BTW tiles of 16 sequences)
+// workgroups per unit of an fc_fwd launch (fc.hip: fc_fwd_waves x FC_BTW tiles of 16 sequences)
+#ifndef FC_BTW
 #define FC_BTW 4
-__host__ __device__ constexpr int fc_fwd_blocks(int B) { return ((B + 15) / 16 + 4 * FC_BTW - 1) / (4 * FC_BTW); }
+#endif
+// wavefronts per fc_fwd workgroup.  The weight fragments are staged once per workgroup (21 KB in the
+// bf16 form: a quarter of the kernel at C2, tools/stampbench), but 8-wave workgroups need 6 waves
+// per SIMD to be resident at once (600 workgroups on 256 CUs) and at 80 registers the train kernels
+// spill; fewer, longer waves (8 tiles each) lost more in latency hiding than the staging saved
+__host__ __device__ constexpr int fc_fwd_waves(int NQ) { return 4; }
+__host__ __device__ constexpr int fc_fwd_blocks(int B, int NQ) {
+    return ((B + 15) / 16 + fc_fwd_waves(NQ) * FC_BTW - 1) / (fc_fwd_waves(NQ) * FC_BTW);
+}
 #define FC_BF_MAXN 96                                     // fc_fwd runs on the bf16 matrix core (exact 3x3 split) up to here
 __host__ __device__ constexpr int fc_ks32(int NQ) { return (NQ + 31) / 32; }   // 32-wide k-steps of the bf16 form
 // passA / passB split the w tiles into groups of WGT (one wave / workgroup per group)

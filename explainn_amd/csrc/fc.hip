@@ -72,28 +72,33 @@ __device__ __forceinline__ void fc_epilogue_tile(const f32x4& acc, int t, int g,
 }
 
 // Workgroup total of the z moments (fixed order: lanes by butterfly, waves 0..3) -> z12p[u][bx]
+template <int W>
 __device__ __forceinline__ void fc_zmom_finish(double s1, double s2, double* __restrict__ z12p, int u,
                                                int bx, int nbx, int wave, int lane) {
-    __shared__ double zred[4][2];
+    __shared__ double zred[W][2];
     // only lanes 0..15 (g = 0) hold sums: four butterfly steps bring their total to lane 0
 #pragma unroll
     for (int off = 8; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
     if (lane == 0) { zred[wave][0] = s1; zred[wave][1] = s2; }
     __syncthreads();
     if (wave == 0 && lane == 0) {
+        double a = 0, b = 0;
+#pragma unroll
+        for (int i = 0; i < W; ++i) { a += zred[i][0]; b += zred[i][1]; }
         double* dst = z12p + ((size_t)u * nbx + bx) * 2;
-        dst[0] = (zred[0][0] + zred[1][0]) + (zred[2][0] + zred[3][0]);
-        dst[1] = (zred[0][1] + zred[1][1]) + (zred[2][1] + zred[3][1]);
+        dst[0] = a; dst[1] = b;
     }
 }
 
 // FC_BTW (common.h): 16-sequence tiles per wavefront in fc_fwd
-#define PB_BTW 4                     // ... in passB
+#ifndef PB_BTW
+#define PB_BTW 4                     // 16-sequence tiles per wavefront in passB
+#endif
 #define FC_AHEAD 3                   // A-fragment reads in flight ahead of their MFMAs in the bf16 fc_fwd
 
 // MODE: 0 eval, 1 train without dropout, 2 train + counter-based generator, 3 train + keep-mask
 template <int NQ, int MODE>
-__global__ __launch_bounds__(256) void fc_fwd_kernel(
+__global__ __launch_bounds__(64 * fc_fwd_waves(NQ)) void fc_fwd_kernel(
     const float* __restrict__ ext, const float* __restrict__ alpha,
     const float* __restrict__ shift, const float* __restrict__ A2f, const float* __restrict__ sh2,
     const float* __restrict__ V2, uint4* __restrict__ bits, float* __restrict__ zout,
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(
     const float* __restrict__ b3, const float* __restrict__ rm3, const float* __restrict__ rv3,
     float* __restrict__ oout, int n, int Bs, int B, int U, const uint32_t* __restrict__ seed_dev,
     double* __restrict__ z12p) {
-    constexpr int NK4 = fc_nk4(NQ), NK4Q = fc_nk4q(NQ);
+    constexpr int NK4 = fc_nk4(NQ), NK4Q = fc_nk4q(NQ), FW = fc_fwd_waves(NQ), NTH = 64 * FW;
     constexpr bool TRAIN = MODE != 0;
     // a captured step (hipGraph) reads its dropout seed from device memory, so that replays can
     // use a new one; direct launches pass it by value
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(
     const int u = blockIdx.y, bx = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
     const float* __restrict__ eu = ext + (size_t)u * n * Bs;
-    const int bt0 = (bx * 4 + wave) * FC_BTW;
+    const int bt0 = (bx * FW + wave) * FC_BTW;
     STAMP(0);
     // the first tile's raw pooled extremes are requested before the weight fragments are staged:
     // one memory round trip covers both
@@ -129,13 +134,13 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(
         // Af[(t*NK4Q + sq)*64 + l].{x,y,z,w} = A2[16t + (l&15)][4*(4sq+e) + (l>>4)], e = 0..3
         const float4* src = reinterpret_cast<const float4*>(A2f) + (size_t)u * FC_MT * NK4Q * 64;
         constexpr int N4 = FC_MT * NK4Q * 64;
-        float4 tv[(N4 + 255) / 256];
+        float4 tv[(N4 + NTH - 1) / NTH];
 #pragma unroll
-        for (int i = 0; i < (N4 + 255) / 256; ++i)
-            tv[i] = (tid + i * 256 < N4) ? src[tid + i * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < (N4 + NTH - 1) / NTH; ++i)
+            tv[i] = (tid + i * NTH < N4) ? src[tid + i * NTH] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int i = 0; i < (N4 + 255) / 256; ++i)
-            if (tid + i * 256 < N4) Af[tid + i * 256] = tv[i];
+        for (int i = 0; i < (N4 + NTH - 1) / NTH; ++i)
+            if (tid + i * NTH < N4) Af[tid + i * NTH] = tv[i];
     }
     if (tid < FC_MT * 16) {
         sh2s[tid] = tid < FC_H ? sh2[(size_t)u * FC_H + tid] : 0.f;
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(
             }
         }
     }
-    if (TRAIN) fc_zmom_finish(zs1, zs2, z12p, u, bx, gridDim.x, wave, lane);
+    if (TRAIN) fc_zmom_finish<FW>(zs1, zs2, z12p, u, bx, gridDim.x, wave, lane);
     STAMP(4);
 }
 
@@ -235,7 +240,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 fbf16x8;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <int NQ, int MODE>
-__global__ __launch_bounds__(256, fc_ks32(NQ) == 1 ? 5 : 2) void fc_fwd_bf_kernel(
+__global__ __launch_bounds__(64 * fc_fwd_waves(NQ), fc_ks32(NQ) == 1 ? 5 : 2) void fc_fwd_bf_kernel(
     const float* __restrict__ ext, const float* __restrict__ alpha,
     const float* __restrict__ shift, const uint32_t* __restrict__ A2h, const float* __restrict__ sh2,
     const float* __restrict__ V2, uint4* __restrict__ bits, float* __restrict__ zout,
@@ -244,7 +249,7 @@ __global__ __launch_bounds__(256, fc_ks32(NQ) == 1 ? 5 : 2) void fc_fwd_bf_kerne
     const float* __restrict__ b3, const float* __restrict__ rm3, const float* __restrict__ rv3,
     float* __restrict__ oout, int n, int Bs, int B, int U, const uint32_t* __restrict__ seed_dev,
     double* __restrict__ z12p) {
-    constexpr int KS = fc_ks32(NQ);
+    constexpr int KS = fc_ks32(NQ), FW = fc_fwd_waves(NQ), NTH = 64 * FW;
     constexpr bool TRAIN = MODE != 0;
     if (MODE == 2 && seed_dev) { seed_lo = seed_dev[0]; seed_hi = seed_dev[1]; }
     extern __shared__ __attribute__((aligned(16))) float fsm[];
@@ -254,7 +259,7 @@ __global__ __launch_bounds__(256, fc_ks32(NQ) == 1 ? 5 : 2) void fc_fwd_bf_kerne
     const int u = blockIdx.y, bx = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
     const float* __restrict__ eu = ext + (size_t)u * n * Bs;
-    const int bt0 = (bx * 4 + wave) * FC_BTW;
+    const int bt0 = (bx * FW + wave) * FC_BTW;
     STAMP(0);
     // the first tile's raw pooled extremes are requested before the weight fragments are staged
     float raw[KS][8];
@@ -268,12 +273,12 @@ __global__ __launch_bounds__(256, fc_ks32(NQ) == 1 ? 5 : 2) void fc_fwd_bf_kerne
     {
         const u32x4* src = reinterpret_cast<const u32x4*>(A2h) + (size_t)u * FC_MT * KS * 3 * 64;
         constexpr int N4 = FC_MT * KS * 3 * 64;
-        u32x4 tv[(N4 + 255) / 256];
+        u32x4 tv[(N4 + NTH - 1) / NTH];
 #pragma unroll
-        for (int i = 0; i < (N4 + 255) / 256; ++i) tv[i] = src[min(tid + i * 256, N4 - 1)];
+        for (int i = 0; i < (N4 + NTH - 1) / NTH; ++i) tv[i] = src[min(tid + i * NTH, N4 - 1)];
 #pragma unroll
-        for (int i = 0; i < (N4 + 255) / 256; ++i)
-            if (tid + i * 256 < N4) Ah[tid + i * 256] = tv[i];
+        for (int i = 0; i < (N4 + NTH - 1) / NTH; ++i)
+            if (tid + i * NTH < N4) Ah[tid + i * NTH] = tv[i];
     }
     if (tid < FC_MT * 16) {
         sh2s[tid] = tid < FC_H ? sh2[(size_t)u * FC_H + tid] : 0.f;
@@ -382,7 +387,7 @@ __global__ __launch_bounds__(256, fc_ks32(NQ) == 1 ? 5 : 2) void fc_fwd_bf_kerne
             }
         }
     }
-    if (TRAIN) fc_zmom_finish(zs1, zs2, z12p, u, bx, gridDim.x, wave, lane);
+    if (TRAIN) fc_zmom_finish<FW>(zs1, zs2, z12p, u, bx, gridDim.x, wave, lane);
     STAMP(4);
 }
 
@@ -403,13 +408,13 @@ static void fc_fwd_launch_nm(explainn_ctx* c, const explainn_params* p, int B, d
                              hipStream_t s) {
     const uint32_t* sd = c->capturing ? c->seed_dev : (const uint32_t*)nullptr;
     if constexpr (N <= FC_BF_MAXN)
-        hipLaunchKernelGGL((fc_fwd_bf_kernel<N, MODE>), grid, dim3(256), fc_fwd_bf_lds<N>(), s, c->ext,
+        hipLaunchKernelGGL((fc_fwd_bf_kernel<N, MODE>), grid, dim3(64 * fc_fwd_waves(N)), fc_fwd_bf_lds<N>(), s, c->ext,
                            c->alpha, c->shift, reinterpret_cast<const uint32_t*>(c->A2h), c->sh2,
                            p->fc2_w, c->bits, c->z, keep_mask, thresh, scale, (uint32_t)seed,
                            (uint32_t)(seed >> 32), p->fc2_b, p->bn3_w, p->bn3_b, p->bn3_rm, p->bn3_rv,
                            c->o, c->n, c->Bs, B, c->U, sd, c->z12p);
     else
-        hipLaunchKernelGGL((fc_fwd_kernel<N, MODE>), grid, dim3(256), fc_fwd_lds<N>(), s, c->ext,
+        hipLaunchKernelGGL((fc_fwd_kernel<N, MODE>), grid, dim3(64 * fc_fwd_waves(N)), fc_fwd_lds<N>(), s, c->ext,
                            c->alpha, c->shift, c->A2f, c->sh2, p->fc2_w, c->bits, c->z, keep_mask,
                            thresh, scale, (uint32_t)seed, (uint32_t)(seed >> 32), p->fc2_b, p->bn3_w,
                            p->bn3_b, p->bn3_rm, p->bn3_rv, c->o, c->n, c->Bs, B, c->U, sd, c->z12p);
@@ -432,7 +437,7 @@ static int fc_fwd_configure_nm() {
 int launch_fc_fwd(explainn_ctx* c, const explainn_params* p, int B, bool train,
                   const uint8_t* keep_mask, float drop_p, uint64_t seed, hipStream_t s) {
     const int tiles = (B + 15) / 16;
-    const dim3 grid(fc_fwd_blocks(B), c->U);
+    const dim3 grid(fc_fwd_blocks(B, c->NQ), c->U);
     int mode = train ? 1 : 0;
     float scale = 1.f;
     uint32_t thresh = 0;
@@ -475,6 +480,128 @@ int launch_fc_fwd(explainn_ctx* c, const explainn_params* p, int B, bool train,
 // 4-byte LDS reads per (channel-tile pair, 32 sequences), most of them broadcasts.  The next
 // super-tile's loads are in flight during the MFMAs.
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// The head backward (final-layer gradients, BatchNorm3 backward -> dz) for few tasks, as passA's
+// prologue: it was a launch of its own (one block per unit, ~10 us at C2 for 300 x 1024 values).
+// Every passA wave needs dz of its own batch chunk, and dz needs two sums over the unit's WHOLE
+// batch (BatchNorm3's backward), so every wave makes that pass itself (o, zhat, and the loss
+// gradient recomputed from logits/targets or read: a few loads per sequence out of L2), then
+// writes dz for its chunk -- the main loop below (and passB) read it from memory; a lane reads back
+// what it wrote itself.  The chunk-0 wave of a unit also owns the unit's parameter gradients, the
+// (unit 0, chunk 0) wave the combiner bias gradient and the loss value.  fp64 sums, lanes by
+// butterfly: fixed order.
+// ---------------------------------------------------------------------------------------------
+// d loss / d logit from (x = dlogit given | x = logit, t = target)
+__device__ __forceinline__ float pa_dl_of(const pa_head_args& h, float invN, float x, float t) {
+    if (h.mode == 1) return x;
+    if (h.kind == EXPLAINN_LOSS_BCE_WITH_LOGITS) return (1.0f / (1.0f + expf(-x)) - t) * invN;
+    return 2.0f * (x - t) * invN;
+}
+__device__ __forceinline__ float pa_dl(const pa_head_args& h, float invN, int i) {
+    return h.mode == 1 ? h.dl[i] : pa_dl_of(h, invN, h.logits[i], h.y[i]);
+}
+
+__device__ __forceinline__ void pa_head_prologue(const pa_head_args& h, int u, int ch, int grp, int lane,
+                                              int bbeg, int bend, int Bs, int B, int U) {
+    const int T = h.T;
+    const float invN = 1.0f / (float)(B * T);
+    const float* __restrict__ ou = h.o + (size_t)u * Bs;
+    const float* __restrict__ zh = h.zhat + (size_t)u * Bs;
+    float wf[PA_HEAD_MAX_T];
+#pragma unroll
+    for (int t = 0; t < PA_HEAD_MAX_T; ++t) wf[t] = t < T ? h.Wf[(size_t)t * U + u] : 0.f;
+    const bool owner = ch == 0 && grp == 0;
+    const bool first = owner && u == 0;
+    double s1 = 0, s2 = 0, gw[PA_HEAD_MAX_T], gb[PA_HEAD_MAX_T], lacc = 0;
+#pragma unroll
+    for (int t = 0; t < PA_HEAD_MAX_T; ++t) { gw[t] = 0; gb[t] = 0; }
+    // eight 64-sequence slices per round trip: every load of a batch is issued before the first use
+    constexpr int PF = 8;
+    for (int b0 = 0; b0 < B; b0 += 64 * PF) {
+        float ovq[PF], zvq[PF], xq[PF][PA_HEAD_MAX_T], yq[PF][PA_HEAD_MAX_T];
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const int bc = min(b0 + 64 * q + lane, B - 1);
+            ovq[q] = ou[bc]; zvq[q] = zh[bc];
+#pragma unroll
+            for (int t = 0; t < PA_HEAD_MAX_T; ++t) {
+                xq[q][t] = 0.f; yq[q][t] = 0.f;
+                if (t < T) {
+                    if (h.mode == 1) xq[q][t] = h.dl[bc * T + t];
+                    else { xq[q][t] = h.logits[bc * T + t]; yq[q][t] = h.y[bc * T + t]; }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            KEEP(ovq[q]); KEEP(zvq[q]);
+#pragma unroll
+            for (int t = 0; t < PA_HEAD_MAX_T; ++t) { KEEP(xq[q][t]); KEEP(yq[q][t]); }
+        }
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const bool live = b0 + 64 * q + lane < B;
+            const float ov = ovq[q], zv = zvq[q];
+            float dob = 0.f;
+#pragma unroll
+            for (int t = 0; t < PA_HEAD_MAX_T; ++t) {
+                if (t >= T) continue;
+                const float dlv = pa_dl_of(h, invN, xq[q][t], yq[q][t]);
+                dob = fmaf(dlv, wf[t], dob);
+                if (owner && live) {
+                    gw[t] = fma((double)dlv, (double)ov, gw[t]);
+                    if (first) {
+                        gb[t] += (double)dlv;
+                        if (h.mode == 2) {
+                            const float x = xq[q][t], tt = yq[q][t];
+                            float l;
+                            if (h.kind == EXPLAINN_LOSS_BCE_WITH_LOGITS) l = fmaxf(x, 0.f) - x * tt + log1pf(expf(-fabsf(x)));
+                            else { const float e = x - tt; l = e * e; }
+                            lacc += (double)l;
+                        }
+                    }
+                }
+            }
+            const float d3 = (live && ov > 0.f) ? dob : 0.f;
+            s1 += (double)d3;
+            s2 = fma((double)d3, live ? (double)zv : 0.0, s2);
+        }
+    }
+    const double S1 = wave_sum_d(s1), S2 = wave_sum_d(s2);
+    const float m1 = (float)(S1 / (double)B), m2 = (float)(S2 / (double)B);
+    const float sc = h.g3[u] / h.sig3[u];
+    float* dzu = h.dz + (size_t)u * Bs;
+    for (int b0 = bbeg; b0 < bend; b0 += 64) {
+        const int b = b0 + lane;
+        if (b < bend) {
+            const float ov = ou[b], zv = zh[b];
+            float dob = 0.f;
+#pragma unroll
+            for (int t = 0; t < PA_HEAD_MAX_T; ++t)
+                if (t < T) dob = fmaf(pa_dl(h, invN, b * T + t), wf[t], dob);
+            const float d3 = ov > 0.f ? dob : 0.f;
+            dzu[b] = sc * (d3 - m1 - zv * m2);
+        }
+    }
+    if (owner) {
+        if (lane == 0) { h.gg3[u] = (float)S2; h.gb3[u] = (float)S1; h.gc2[u] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < PA_HEAD_MAX_T; ++t) {
+            if (t >= T) continue;
+            const double tot = wave_sum_d(gw[t]);
+            if (lane == 0) h.gWf[(size_t)t * U + u] = (float)tot;
+            if (first) {
+                const double ct = wave_sum_d(gb[t]);
+                if (lane == 0) h.gbf[t] = (float)ct;
+            }
+        }
+        if (first && h.mode == 2) {
+            const double tot = wave_sum_d(lacc);
+            if (lane == 0) *h.loss_out = (float)(tot / (double)(B * T));
+        }
+    }
+}
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 #define PA_LD 72                     // bf16 elements per row of the X image (64 sequences + 8 pad)
@@ -490,7 +617,7 @@ __global__ __launch_bounds__(64, 3) void passA_kernel(const float* __restrict__ 
                                                    const uint4* __restrict__ bits,
                                                    float* __restrict__ EQp,
                                                    float* __restrict__ Sep, int n, int Bs, int B,
-                                                   int ACH) {
+                                                   int ACH, const pa_head_args h, int U) {
     constexpr int NS = ns_stride(NQ), WGT = pa_wgt(NQ), ROWS = 16 * WGT;
     __shared__ __attribute__((aligned(16))) uint16_t xt[3 * ROWS * PA_LD];     // [piece][row][sequence] bf16
     __shared__ __attribute__((aligned(16))) uint32_t tw[64 * 4];               // [sequence][4] bit words
@@ -503,6 +630,7 @@ __global__ __launch_bounds__(64, 3) void passA_kernel(const float* __restrict__ 
     const float* __restrict__ eu = ext + (size_t)u * n * Bs;
     const float* __restrict__ dzu = dz + (size_t)u * Bs;
     const uint4* __restrict__ bu = bits + (size_t)u * Bs;
+    if (h.mode) pa_head_prologue(h, u, ch, grp, lane, bbeg, bend, Bs, B, U);
     f32x4 acc[FC_MT][WGT];
 #pragma unroll
     for (int t = 0; t < FC_MT; ++t)
@@ -610,11 +738,13 @@ __global__ __launch_bounds__(64, 3) void passA_kernel(const float* __restrict__ 
     STAMP(3);
 }
 
-int launch_passA(explainn_ctx* c, int B, hipStream_t s) {
+int launch_passA(explainn_ctx* c, int B, const pa_head_args* head, hipStream_t s) {
+    pa_head_args h = {};
+    if (head) h = *head;
 #define CALL(N)                                                                                  \
     hipLaunchKernelGGL(passA_kernel<N>, dim3(c->ACH, c->U, pa_ng(N)), dim3(64), 0, s,            \
                        c->ext, c->alpha, c->shift, c->dz, c->bits, c->EQp, c->Sep, c->n, c->Bs,  \
-                       B, c->ACH)
+                       B, c->ACH, h, c->U)
     NQ_DISPATCH(c->NQ, CALL);
 #undef CALL
     LAUNCH_CHECK();

@@ -279,7 +279,7 @@ int launch_head_fwd(explainn_ctx* c, const explainn_params* p, int B, bool train
                     float* outs, hipStream_t s) {
     if (train && logits && c->T <= HEAD_GEMM_MIN_T && !outs && (size_t)c->U * sizeof(float4) <= 48 * 1024) {
         hipLaunchKernelGGL(logits_bn_kernel, dim3((B + 63) / 64, c->T), dim3(1024),
-                           (size_t)c->U * sizeof(float4), s, c->z, c->z12p, fc_fwd_blocks(B),
+                           (size_t)c->U * sizeof(float4), s, c->z, c->z12p, fc_fwd_blocks(B, c->NQ),
                            p->fc2_b, p->bn3_w, p->bn3_b, p->bn3_rm, p->bn3_rv, p->bn3_nbt, c->zhat,
                            c->o, c->sig3, p->final_w, p->final_b, logits, c->U, c->T, c->Bs, B);
         LAUNCH_CHECK();

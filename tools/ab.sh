@@ -1,4 +1,12 @@
 #!/bin/bash
-# A/B of experiment knobs on the GPU box: each line = one bench run (ms_per_step of the C2 step)
-run() { echo -n "$* : "; env "$@" python3 bench.py --no-cpu-baseline --skip-optimizer --steps 400 --warmup 30 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['roofline']['gpu_ms_per_step_hip_events'])"; }
-for v in "$@"; do run $v; done
+# A/B of library builds on the GPU box: each argument = one library file (or "base" for the in-tree
+# one); prints ms_per_step and the per-stage times of the C2 step
+for v in "$@"; do
+  if [ "$v" = base ]; then unset EXPLAINN_HIP_LIB; else export EXPLAINN_HIP_LIB="$PWD/$v"; fi
+  echo -n "$v : "
+  python3 bench.py --no-cpu-baseline --skip-optimizer --steps 400 --warmup 30 2>/dev/null | python3 -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+k=d['roofline'].get('kernels') or {}
+print(d['ms_per_step'], {n:v['us'] for n,v in k.items() if n in ('fc_fwd','passB','passA','mid','conv_pool','conv_bwd')})"
+done

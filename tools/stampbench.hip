@@ -43,6 +43,7 @@ int main() {
     float* A2f = (float*)dalloc((size_t)U * FC_MT * NK4Q * 256 * 4); float* sh2 = (float*)dalloc(U * 100 * 4); float* V2 = (float*)dalloc(U * 100 * 4);
     std::vector<float> hw((size_t)U * FC_MT * NK4Q * 256); for (auto& v : hw) v = (rand() % 2000) * 1e-3f - 1.f;
     CK(hipMemcpy(A2f, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+    uint32_t* A2h = (uint32_t*)dalloc((size_t)U * FC_MT * fc_ks32(NQ) * 3 * 256 * 4); double* z12p = (double*)dalloc((size_t)U * 8 * 16);
     uint4* bits = (uint4*)dalloc((size_t)U * Bs * 16 + 64); float* z = (float*)dalloc((size_t)U * Bs * 4); float* o = (float*)dalloc((size_t)U * Bs * 4);
     float* dz = (float*)dalloc((size_t)U * Bs * 4 + 64); float* EQp = (float*)dalloc((size_t)U * ACH * 100 * NS * 4); float* Sep = (float*)dalloc((size_t)U * ACH * 100 * 4);
     float* Tt = (float*)dalloc((size_t)U * NW16 * 3072 * 4 + (size_t)(U * 100 + 2) * NS * 8); float* M = (float*)dalloc((size_t)(U * NS + 2) * NS * 8); float* k0p = (float*)dalloc(U * NS * 4);
@@ -57,11 +58,11 @@ int main() {
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
         if (rep) report("qmom", QCH * U, 4, ms);
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((fc_fwd_kernel<26, 2>), dim3(4, U), dim3(256), fc_fwd_lds<26>(), 0, ext, alpha, shift, A2f, sh2, V2, bits, z, (const uint8_t*)nullptr, 19661u, 1.4285715f, 1u, 2u, fz, fz, fz, fz, fz, o, n, Bs, B, U, (const uint32_t*)nullptr);
+        hipLaunchKernelGGL((fc_fwd_bf_kernel<26, 2>), dim3(4, U), dim3(256), fc_fwd_bf_lds<26>(), 0, ext, alpha, shift, A2h, sh2, V2, bits, z, (const uint8_t*)nullptr, 19661u, 1.4285715f, 1u, 2u, fz, fz, fz, fz, fz, o, n, Bs, B, U, (const uint32_t*)nullptr, z12p);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
         if (rep) report("fc_fwd", 4 * U * 4, 5, ms);
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(passA_kernel<26>, dim3(ACH, U, 1), dim3(64), 0, 0, ext, alpha, shift, dz, bits, EQp, Sep, n, Bs, B, ACH);
+        hipLaunchKernelGGL(passA_kernel<26>, dim3(ACH, U, 1), dim3(64), 0, 0, ext, alpha, shift, dz, bits, EQp, Sep, n, Bs, B, ACH, pa_head_args{}, U);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
         if (rep) report("passA", ACH * U, 4, ms);
         CK(hipEventRecord(e0));
@@ -82,10 +83,10 @@ int main() {
         double* qbar = (double*)dalloc((size_t)U * NS * 8); float* A2 = (float*)dalloc((size_t)U * 100 * NS * 4);
         float* sig2 = (float*)dalloc(U * 100 * 4); std::vector<float> ones(U * 100, 1.f); CK(hipMemcpy(sig2, ones.data(), U * 100 * 4, hipMemcpyHostToDevice));
         float* md = (float*)dalloc((size_t)U * 100 * n * 4 + 4096);
-        size_t cps = (size_t)(NT * 16 + k * 5) * 16 + (size_t)(19 + 10) * 64 * 4;
+        size_t cps = (size_t)(NT * 16 + k * 5) * 16 + (size_t)(8 + 5) * 64 * 4;   // 8-window code tiles (convpool.hip: conv_pool_lds)
         for (int rep = 0; rep < 2; ++rep) {
             CK(hipEventRecord(e0));
-            hipLaunchKernelGGL(conv_pool_kernel<19>, dim3(16 * 4, U4 / 4), dim3(64), cps, 0, pk2, nmask, (const float4*)lut, Wt, alpha, U, ext, idx, n, Bs, PW, NW, 4);
+            hipLaunchKernelGGL((conv_pool_kernel<19, 8>), dim3(16 * 4, U4 / 4), dim3(64), cps, 0, pk2, nmask, (const float4*)lut, Wt, alpha, U, ext, idx, n, Bs, PW, NW, 4);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
             if (rep) report("conv_pool", 16 * 4 * (U4 / 4), 3, ms);
             CK(hipEventRecord(e0));
@@ -93,7 +94,7 @@ int main() {
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
             if (rep) report("conv_bwd", 8 * U, 4, ms);
             CK(hipEventRecord(e0));
-            hipLaunchKernelGGL(prep2_kernel<true>, dim3(U), dim3(1024), prep2_lds(n, NS), 0, fc1_w, sh2, sh2, sh2, md, md + U * 100, (int64_t*)nullptr, qs0, S1p, S2p, qbar, VC, A2, A2f, sh2, sig2, n, NS, NK4Q, B, QCH);
+            hipLaunchKernelGGL(prep2_kernel<true>, dim3(U), dim3(1024), prep2_lds(n, NS), 0, fc1_w, sh2, sh2, sh2, md, md + U * 100, (int64_t*)nullptr, qs0, S1p, S2p, qbar, VC, A2, (float*)nullptr, sh2, sig2, n, NS, NK4Q, B, QCH, A2h, fc_ks32(NQ));
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
             if (rep) report("prep2", U * 16, 4, ms);
             CK(hipEventRecord(e0));
