@@ -202,6 +202,9 @@ def test_adam_trajectory_golden(golden):
     # mid_big, passB<140>/<84>, fc_fwd<NQ > 32> -- the code paths configs C4 / C5 run
     (3, 19, 1000, 2, 300, 0.01),    # n = 140, 3 chunks of 128 (last one 44 sequences)
     (2, 19, 600, 5, 700, 0.02),     # n = 83, 6 chunks (last one 60)
+    (3, 19, 450, 1, 90, 0.0),       # n = 61 -> bucket 64: two 32-wide k-steps of the bf16 fc_fwd
+    (4, 19, 61, 2, 600, 0.0),       # few tasks, batch > 512: the per-unit head backward kernel (smaller
+                                    # batches run it inside passA)
 ])
 def test_train_step_vs_oracle(U, k, L, T, B, nfrac):
     sd = orc.random_state_dict(U, k, L, T, seed=U + L)
