@@ -2,7 +2,7 @@
 """Print a rocprofv3 kernel_stats.csv as a short table (per-step microseconds)."""
 import csv, sys, glob
 path = sys.argv[1]
-steps = float(sys.argv[2]) if len(sys.argv) > 2 else None
+steps = float(sys.argv[2]) if len(sys.argv) > 2 else None   # (a third argument, the bench line, is for install_profiles.py)
 f = glob.glob(path + "/*/*kernel_stats.csv")[0] if not path.endswith(".csv") else path
 rows = list(csv.DictReader(open(f)))
 tot = 0.0
