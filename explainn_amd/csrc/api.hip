@@ -188,7 +188,7 @@ extern "C" int explainn_create(explainn_ctx** out, int cnn_units, int kernel_siz
         if (q > cap) q = cap;
         if (q < 1) q = 1;
         c->QCH = q;
-        int a = (max_batch + 127) / 128;
+        int a = (max_batch + 255) / 256;                 // passA: two 128-sequence waves per chunk (fc.hip)
         if (a > 16) a = 16;
         if (a < 1) a = 1;
         c->ACH = a;

@@ -609,8 +609,9 @@ __host__ __device__ constexpr int pa_nw16(int NQ) { return (NQ + 1 + 15) / 16; }
 __host__ __device__ constexpr int pa_wgt(int NQ) { return pa_nw16(NQ) <= 2 ? pa_nw16(NQ) : 3; }
 __host__ __device__ constexpr int pa_ng(int NQ) { return (pa_nw16(NQ) + pa_wgt(NQ) - 1) / pa_wgt(NQ); }
 
+#define PA_WAVES 2                    // wavefronts per passA workgroup: their tiles are added in LDS before the store
 template <int NQ>
-__global__ __launch_bounds__(64, 3) void passA_kernel(const float* __restrict__ ext,
+__global__ __launch_bounds__(64 * PA_WAVES, 3) void passA_kernel(const float* __restrict__ ext,
                                                    const float* __restrict__ alpha,
                                                    const float* __restrict__ shift,
                                                    const float* __restrict__ dz,
@@ -619,18 +620,25 @@ __global__ __launch_bounds__(64, 3) void passA_kernel(const float* __restrict__ 
                                                    float* __restrict__ Sep, int n, int Bs, int B,
                                                    int ACH, const pa_head_args h, int U) {
     constexpr int NS = ns_stride(NQ), WGT = pa_wgt(NQ), ROWS = 16 * WGT;
-    __shared__ __attribute__((aligned(16))) uint16_t xt[3 * ROWS * PA_LD];     // [piece][row][sequence] bf16
-    __shared__ __attribute__((aligned(16))) uint32_t tw[64 * 4];               // [sequence][4] bit words
-    const int u = blockIdx.y, ch = blockIdx.x, grp = blockIdx.z, lane = threadIdx.x;
+    // per wave: the X image [piece][row][sequence] bf16 and the bit words [sequence][4]; the region of
+    // wave 1 doubles as the buffer its accumulator tile crosses to wave 0 in at the end
+    constexpr int XT_HALFS = 3 * ROWS * PA_LD, REGION = XT_HALFS * 2 + 64 * 4 * 4;
+    static_assert(REGION >= FC_MT * WGT * 64 * 16, "accumulator tile must fit the wave's LDS region");
+    __shared__ __attribute__((aligned(16))) unsigned char pal[PA_WAVES][REGION];
+    const int u = blockIdx.y, ch = blockIdx.x, grp = blockIdx.z, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: LDS bases stay scalar
+    uint16_t* xt = reinterpret_cast<uint16_t*>(pal[wave]);
+    uint32_t* tw = reinterpret_cast<uint32_t*>(pal[wave] + XT_HALFS * 2);
     const int c = lane & 15, g = lane >> 4;
     const int w0 = grp * ROWS;                         // first column of this group
-    const int per = ((((B + ACH - 1) / ACH) + 63) / 64) * 64;
-    const int bbeg = ch * per, bend = min(B, bbeg + per);
+    // a workgroup owns one of the ACH batch chunks; its PA_WAVES waves split it in 64-sequence tiles
+    const int per = ((((B + ACH - 1) / ACH) + 64 * PA_WAVES - 1) / (64 * PA_WAVES)) * (64 * PA_WAVES);
+    const int bbeg = min(B, ch * per + wave * (per / PA_WAVES)), bend = min(B, bbeg + per / PA_WAVES);
     const float a1 = alpha[u], sh1 = shift[u];
     const float* __restrict__ eu = ext + (size_t)u * n * Bs;
     const float* __restrict__ dzu = dz + (size_t)u * Bs;
     const uint4* __restrict__ bu = bits + (size_t)u * Bs;
-    if (h.mode) pa_head_prologue(h, u, ch, grp, lane, bbeg, bend, Bs, B, U);
+    if (h.mode) pa_head_prologue(h, u, ch + wave, grp, lane, bbeg, bend, Bs, B, U);   // (owner: chunk 0, wave 0)
     f32x4 acc[FC_MT][WGT];
 #pragma unroll
     for (int t = 0; t < FC_MT; ++t)
@@ -717,6 +725,29 @@ __global__ __launch_bounds__(64, 3) void passA_kernel(const float* __restrict__ 
         __builtin_amdgcn_wave_barrier();
     }
     STAMP(2);
+    // the tile of wave 1 is added to wave 0's through LDS (fixed order), halving the partial sums the
+    // small-algebra kernel has to fetch: its 300 blocks pull them all in one burst at kernel start
+    __syncthreads();
+    {
+        float4* red = reinterpret_cast<float4*>(pal[1]);
+        if (wave == 1) {
+#pragma unroll
+            for (int t = 0; t < FC_MT; ++t)
+#pragma unroll
+                for (int j = 0; j < WGT; ++j)
+                    red[(t * WGT + j) * 64 + lane] = make_float4(acc[t][j][0], acc[t][j][1], acc[t][j][2], acc[t][j][3]);
+        }
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int t = 0; t < FC_MT; ++t)
+#pragma unroll
+            for (int j = 0; j < WGT; ++j) {
+                const float4 v = red[(t * WGT + j) * 64 + lane];
+                acc[t][j][0] += v.x; acc[t][j][1] += v.y; acc[t][j][2] += v.z; acc[t][j][3] += v.w;
+                if ((t * WGT + j) % 4 == 3) __builtin_amdgcn_sched_barrier(0);   // four reads in flight, not 14
+            }
+    }
     // D[r][w]: lane holds column w = w0 + 16j + c, rows r = 16t + 4g + i (i = 0..3 consecutive);
     // column n carries Se.  The partial sums are stored w-major, EQp[..][w][r], so that a lane's four
     // rows are one 16-byte store (r-major they were 56 four-byte stores per lane, each instruction
@@ -742,7 +773,7 @@ int launch_passA(explainn_ctx* c, int B, const pa_head_args* head, hipStream_t s
     pa_head_args h = {};
     if (head) h = *head;
 #define CALL(N)                                                                                  \
-    hipLaunchKernelGGL(passA_kernel<N>, dim3(c->ACH, c->U, pa_ng(N)), dim3(64), 0, s,            \
+    hipLaunchKernelGGL(passA_kernel<N>, dim3(c->ACH, c->U, pa_ng(N)), dim3(64 * PA_WAVES), 0, s, \
                        c->ext, c->alpha, c->shift, c->dz, c->bits, c->EQp, c->Sep, c->n, c->Bs,  \
                        B, c->ACH, h, c->U)
     NQ_DISPATCH(c->NQ, CALL);
