@@ -430,60 +430,114 @@ __global__ __launch_bounds__(1024) void prep2_kernel(
         float* V1s = Cs + n * n;
         const int ld = n + 1;
         const double invB = 1.0 / (double)B;
-        // V1 into LDS, four elements per thread per pass with their loads issued together (a plain
-        // strided loop with a runtime trip count is one exposed round trip per iteration)
-        for (int e0 = tid; e0 < FC_H * n; e0 += 4 * NT) {
-            float v[4];
+        if (n * n + n <= NT && FC_H * n <= 4 * NT && QCH <= 8) {
+            // small n (the headline shape): ALL of the block's inputs in ONE memory round trip -- V1
+            // (four elements per thread), the S1 and S2 chunk partials (eight each) and the shift --
+            // held in registers across the barrier that the covariance needs.  They were three
+            // dependent round trips (V1 + S1 | S2 | shift), 40 % of the block's cycles by stamps.
+            // 21 values per thread: still under the 64 registers that let two blocks share a CU
+            // (the all-in-one batch tried earlier also merged the k-loop operands and took 96).
+            const float* __restrict__ w1u = fc1_w + (size_t)u * FC_H * n;
+            const float* __restrict__ s1u = S1p + (size_t)u * QCH * NS;
+            const float* __restrict__ s2u = S2p + (size_t)u * QCH * NS * NS;
+            float v[4], pv[8], q0;            // pv: S2 partials (threads < n^2) or S1 partials (the last n)
+            const int tot = FC_H * n;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = fc1_w[(size_t)u * FC_H * n + min(e0 + q * NT, FC_H * n - 1)];
+            for (int q = 0; q < 4; ++q) v[q] = w1u[(uint32_t)min(tid + q * NT, tot - 1)];
+            const int w1 = min(NT - 1 - tid, n - 1);              // the last threads take the S1 sums
+            const int e2 = min(tid, n * n - 1), w2 = e2 / n, wp2 = e2 - w2 * n;
+            const bool takes1 = NT - 1 - tid < n;
+            const float* __restrict__ pbase = takes1 ? s1u + w1 : s2u + (w2 * NS + wp2);
+            const uint32_t pstride = takes1 ? (uint32_t)NS : (uint32_t)(NS * NS);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pv[i] = pbase[(uint32_t)min(i, QCH - 1) * pstride];
+            q0 = qs0[(size_t)u * NS + min(tid, n - 1)];
 #pragma unroll
             for (int q = 0; q < 4; ++q) KEEP(v[q]);
 #pragma unroll
+            for (int i = 0; i < 8; ++i) KEEP(pv[i]);
+            KEEP(q0);
+#pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int e = e0 + q * NT;
-                if (e < FC_H * n) V1s[(e / n) * ld + (e % n)] = v[q];
+                const int e = tid + q * NT;
+                if (e < tot) V1s[(e / n) * ld + (e % n)] = v[q];
             }
-        }
-        // combine the chunk partials (fixed order -> deterministic), eight loads in flight; the last
-        // threads take this so that it overlaps the staging above.  (Issuing these, the covariance
-        // partials below and V1 in ONE batch per thread was tried: shorter waves, longer kernel --
-        // +6 us on the step with the same change in mid_fused.)
-        for (int w = NT - 1 - tid; w < n; w += NT) {
-            double s1 = 0;
-            for (int c0 = 0; c0 < QCH; c0 += 8) {
-                float pv[8];
+            if (takes1) {
+                double s1 = 0;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) pv[i] = S1p[((size_t)u * QCH + min(c0 + i, QCH - 1)) * NS + w];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) KEEP(pv[i]);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) s1 += (c0 + i < QCH) ? (double)pv[i] : 0.0;
+                for (int i = 0; i < 8; ++i) s1 += (i < QCH) ? (double)pv[i] : 0.0;
+                qb[NT - 1 - tid] = s1 * invB;     // mean of (q - s); the shift is added below
             }
-            qb[w] = s1 * invB;                // mean of (q - s); the shift is added below
-        }
-        __syncthreads();
-        for (int e = tid; e < n * n; e += NT) {
-            const int w = e / n, wp = e % n;
-            double s2 = 0;
-            for (int c0 = 0; c0 < QCH; c0 += 8) {     // eight partials in flight, fixed-order sum
-                float pv[8];
+            __syncthreads();
+            if (tid < n * n) {
+                double s2 = 0;
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    pv[i] = S2p[(((size_t)u * QCH + min(c0 + i, QCH - 1)) * NS + w) * NS + wp];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) KEEP(pv[i]);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) s2 += (c0 + i < QCH) ? (double)pv[i] : 0.0;
+                for (int i = 0; i < 8; ++i) s2 += (i < QCH) ? (double)pv[i] : 0.0;
+                // S2 holds sum (q_w - s_w)(q_w' - s_w'); qb = mean of (q - s)
+                Cs[tid] = (float)(s2 * invB - qb[w2] * qb[wp2]);
             }
-            // S2 holds sum (q_w - s_w)(q_w' - s_w'); qb = mean of (q - s)
-            const double cov = s2 * invB - qb[w] * qb[wp];
-            Cs[e] = (float)cov;
-        }
-        __syncthreads();
-        for (int w = tid; w < n; w += NT) {
-            const double v = qb[w] + (double)qs0[(size_t)u * NS + w];
-            qbar[(size_t)u * NS + w] = v;
-            qb[w] = v;                        // from here on qb = mean of q
+            __syncthreads();
+            if (tid < n) {
+                const double vq = qb[tid] + (double)q0;
+                qbar[(size_t)u * NS + tid] = vq;
+                qb[tid] = vq;                     // from here on qb = mean of q
+            }
+        } else {
+            // V1 into LDS, four elements per thread per pass with their loads issued together (a plain
+            // strided loop with a runtime trip count is one exposed round trip per iteration)
+            for (int e0 = tid; e0 < FC_H * n; e0 += 4 * NT) {
+                float v[4];
+    #pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = fc1_w[(size_t)u * FC_H * n + min(e0 + q * NT, FC_H * n - 1)];
+    #pragma unroll
+                for (int q = 0; q < 4; ++q) KEEP(v[q]);
+    #pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int e = e0 + q * NT;
+                    if (e < FC_H * n) V1s[(e / n) * ld + (e % n)] = v[q];
+                }
+            }
+            // combine the chunk partials (fixed order -> deterministic), eight loads in flight; the last
+            // threads take this so that it overlaps the staging above.  (Issuing these, the covariance
+            // partials below and V1 in ONE batch per thread was tried: shorter waves, longer kernel --
+            // +6 us on the step with the same change in mid_fused.)
+            for (int w = NT - 1 - tid; w < n; w += NT) {
+                double s1 = 0;
+                for (int c0 = 0; c0 < QCH; c0 += 8) {
+                    float pv[8];
+    #pragma unroll
+                    for (int i = 0; i < 8; ++i) pv[i] = S1p[((size_t)u * QCH + min(c0 + i, QCH - 1)) * NS + w];
+    #pragma unroll
+                    for (int i = 0; i < 8; ++i) KEEP(pv[i]);
+    #pragma unroll
+                    for (int i = 0; i < 8; ++i) s1 += (c0 + i < QCH) ? (double)pv[i] : 0.0;
+                }
+                qb[w] = s1 * invB;                // mean of (q - s); the shift is added below
+            }
+            __syncthreads();
+            for (int e = tid; e < n * n; e += NT) {
+                const int w = e / n, wp = e % n;
+                double s2 = 0;
+                for (int c0 = 0; c0 < QCH; c0 += 8) {     // eight partials in flight, fixed-order sum
+                    float pv[8];
+    #pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        pv[i] = S2p[(((size_t)u * QCH + min(c0 + i, QCH - 1)) * NS + w) * NS + wp];
+    #pragma unroll
+                    for (int i = 0; i < 8; ++i) KEEP(pv[i]);
+    #pragma unroll
+                    for (int i = 0; i < 8; ++i) s2 += (c0 + i < QCH) ? (double)pv[i] : 0.0;
+                }
+                // S2 holds sum (q_w - s_w)(q_w' - s_w'); qb = mean of (q - s)
+                const double cov = s2 * invB - qb[w] * qb[wp];
+                Cs[e] = (float)cov;
+            }
+            __syncthreads();
+            for (int w = tid; w < n; w += NT) {
+                const double v = qb[w] + (double)qs0[(size_t)u * NS + w];
+                qbar[(size_t)u * NS + w] = v;
+                qb[w] = v;                        // from here on qb = mean of q
+            }
         }
         __syncthreads();
         STAMP(1);
