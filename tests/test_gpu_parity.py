@@ -713,6 +713,31 @@ def test_eval_tables_follow_parameter_changes():
     check("after re-assigning a Parameter")
 
 
+def test_fc_bf16_piece_products_are_fp32_accurate(monkeypatch):
+    """fc_fwd runs on the bf16 matrix core with BOTH fp32 operands split exactly into three bf16
+    pieces and all nine piece products accumulated in fp32.  Claim under test: that is
+    an fp32 computation, not a reduced-precision one -- against the fp64 oracle the unit outputs are
+    as close as those of the fp32-MFMA form of the same contraction (the single-launch eval kernel,
+    v_mfma_f32_16x16x4_f32), at rounding level (a bf16-input GEMM would be off by ~1e-3)."""
+    U, k, L, T, B = 24, 19, 200, 1, 256
+    sd = orc.random_state_dict(U, k, L, T, seed=77)
+    x = orc.random_onehot(B, L, seed=78)
+    ref = orc.unit_outputs(sd, x, dtype=np.float64)
+    m = _model(sd, U, k, L, T).eval()
+    xt = torch.from_numpy(x).cuda()
+    with torch.no_grad():
+        monkeypatch.delenv("EXPLAINN_EVAL_FUSED", raising=False)
+        bf = _np(m.linears(xt.repeat(1, U, 1)))
+        monkeypatch.setenv("EXPLAINN_EVAL_FUSED", "1")
+        f32 = _np(m.linears(xt.repeat(1, U, 1)))
+    monkeypatch.delenv("EXPLAINN_EVAL_FUSED", raising=False)
+    scale = max(1.0, np.abs(ref).max())
+    e_bf, e_f32 = np.abs(bf - ref).max() / scale, np.abs(f32 - ref).max() / scale
+    print("unit outputs vs fp64: bf16 nine-piece form %.2e, fp32 MFMA form %.2e" % (e_bf, e_f32))
+    assert e_bf <= 3e-6 and e_f32 <= 3e-6, (e_bf, e_f32)
+    assert e_bf <= 2 * e_f32 + 2e-7, (e_bf, e_f32)
+
+
 def test_single_launch_eval_kernel(monkeypatch):
     """EXPLAINN_EVAL_FUSED=1: the eval forward as pack + ONE launch (filter bank -> pooling -> exp
     -> FC -> combiner with the pooled activations in LDS, partial logits combined by the last
