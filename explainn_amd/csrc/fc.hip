@@ -611,7 +611,7 @@ __host__ __device__ constexpr int pa_ng(int NQ) { return (pa_nw16(NQ) + pa_wgt(N
 
 #define PA_WAVES 2                    // wavefronts per passA workgroup: their tiles are added in LDS before the store
 template <int NQ>
-__global__ __launch_bounds__(64 * PA_WAVES, 3) void passA_kernel(const float* __restrict__ ext,
+__global__ __launch_bounds__(64 * PA_WAVES, pa_wgt(NQ) <= 2 ? 3 : 2) void passA_kernel(const float* __restrict__ ext,
                                                    const float* __restrict__ alpha,
                                                    const float* __restrict__ shift,
                                                    const float* __restrict__ dz,
