@@ -205,6 +205,7 @@ def test_adam_trajectory_golden(golden):
     (3, 19, 450, 1, 90, 0.0),       # n = 61 -> bucket 64: two 32-wide k-steps of the bf16 fc_fwd
     (4, 19, 61, 2, 600, 0.0),       # few tasks, batch > 512: the per-unit head backward kernel (smaller
                                     # batches run it inside passA)
+    (1100, 5, 40, 2, 70, 0.0),      # more units than threads in the combiner block that finishes BatchNorm3
 ])
 def test_train_step_vs_oracle(U, k, L, T, B, nfrac):
     sd = orc.random_state_dict(U, k, L, T, seed=U + L)
