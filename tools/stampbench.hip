@@ -10,15 +10,71 @@
 #include <vector>
 __device__ unsigned long long g_stamps[1 << 20];
 void explainn_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vprintf(fmt, ap); va_end(ap); printf("\n"); }
+#include "../explainn_amd/csrc/common.h"
+#ifdef BALANCE
+// -DBALANCE: stamp 0 also records where the wave runs (slot 7: HW_ID | XCC_ID << 32) and the report
+// becomes a load-balance table: waves per SIMD, wave time by co-residency, start skew
+#undef STAMP
+#define STAMP(i)                                                                                  \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                               \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        if ((threadIdx.x & 63) == 0) {                                                            \
+            const size_t s_ = ((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * (blockDim.x / 64) + threadIdx.x / 64) * 8; \
+            g_stamps[s_ + (i)] = t_;                                                              \
+            if ((i) == 0) g_stamps[s_ + 7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | \
+                                             ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); \
+        }                                                                                         \
+    } while (0)
+#endif
 #include "../explainn_amd/csrc/prep.hip"
 #include "../explainn_amd/csrc/fc.hip"
 #include "../explainn_amd/csrc/bwd.hip"
 #include "../explainn_amd/csrc/convpool.hip"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
+#ifdef BALANCE
+#include <map>
+static void balance(const char* name, const std::vector<unsigned long long>& h, int waves, int nst) {
+    // group waves by (xcc, se, cu, simd); gfx9 HW_ID: wave[3:0] simd[5:4] pipe[7:6] cu[11:8] sh[12] se[15:13]
+    struct W { unsigned long long t0, t1; };
+    std::map<unsigned, std::vector<W>> simd;
+    unsigned long long tmin = ~0ull, tmax = 0;
+    for (int w = 0; w < waves; ++w) {
+        const unsigned long long t0 = h[w * 8], t1 = h[w * 8 + nst - 1], id = h[w * 8 + 7];
+        if (!t0 || !t1) continue;
+        const unsigned hw = (unsigned)id, xcc = (unsigned)(id >> 32) & 15;
+        const unsigned key = (xcc << 16) | (((hw >> 13) & 7) << 12) | (((hw >> 8) & 15) << 4) | ((hw >> 4) & 3);
+        simd[key].push_back({t0, t1});
+        tmin = std::min(tmin, t0); tmax = std::max(tmax, t1);
+    }
+    std::map<int, std::vector<double>> by_n;          // waves on the SIMD -> wave durations
+    std::map<int, int> nsimd;
+    std::vector<double> busy, skew;
+    for (auto& kv : simd) {
+        const int nw = (int)kv.second.size();
+        nsimd[nw]++;
+        unsigned long long a = ~0ull, b = 0;
+        for (auto& w : kv.second) { by_n[nw].push_back((double)(w.t1 - w.t0)); a = std::min(a, w.t0); b = std::max(b, w.t1); skew.push_back((double)(w.t0 - tmin)); }
+        busy.push_back((double)(b - a));
+    }
+    std::sort(busy.begin(), busy.end()); std::sort(skew.begin(), skew.end());
+    printf("%-10s BALANCE: %zu SIMDs used, kernel span %.0f cyc; SIMD busy span p50 %.0f max %.0f; wave start skew p50 %.0f p90 %.0f max %.0f\n",
+           name, simd.size(), (double)(tmax - tmin), busy[busy.size() / 2], busy.back(), skew[skew.size() / 2], skew[skew.size() * 9 / 10], skew.back());
+    for (auto& kv : by_n) {
+        auto& d = kv.second; std::sort(d.begin(), d.end());
+        printf("           %d waves/SIMD: %d SIMDs, wave time p50 %.0f p90 %.0f max %.0f\n", kv.first, nsimd[kv.first], d[d.size() / 2], d[d.size() * 9 / 10], d.back());
+    }
+}
+#endif
+
 static void report(const char* name, int waves, int nst, float ms) {
     std::vector<unsigned long long> h((size_t)waves * 8);
     CK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_stamps), h.size() * 8));
+#ifdef BALANCE
+    balance(name, h, waves, nst);
+#endif
     printf("%-10s event %.1f us | median cycles per phase:", name, ms * 1e3);
     for (int p = 1; p < nst; ++p) {
         std::vector<double> d;
