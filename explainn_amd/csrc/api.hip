@@ -263,7 +263,7 @@ extern "C" int explainn_forward_eval(explainn_ctx* c, const float* x, int B,
         if (c->T > 8) TRY(launch_head_fwd(c, p, B, false, logits, nullptr, s));
         return EXPLAINN_OK;
     }
-    TRY(launch_conv_pool(c, p, B, s));
+    TRY(launch_conv_pool(c, p, B, false, s));
     TRY(launch_fc_fwd(c, p, B, false, nullptr, 0.f, 0, s));
     TRY(launch_head_fwd(c, p, B, false, logits, nullptr, s));
     return EXPLAINN_OK;
@@ -280,7 +280,7 @@ extern "C" int explainn_unit_outputs(explainn_ctx* c, const float* x, int B,
     } else if (eval_fused_available(c)) {
         TRY(launch_eval_fused(c, p, B, nullptr, true, s));
     } else {
-        TRY(launch_conv_pool(c, p, B, s));
+        TRY(launch_conv_pool(c, p, B, false, s));
         TRY(launch_fc_fwd(c, p, B, false, nullptr, 0.f, 0, s));
     }
     TRY(launch_head_fwd(c, p, B, false, nullptr, outs, s));
@@ -372,7 +372,7 @@ extern "C" int explainn_forward_train(explainn_ctx* c, const float* x, int B,
     // -- the step is 4 us shorter.)
     STAGE(ST_MOMENTS, launch_moments(c, B, s));
     STAGE(ST_PREP1, launch_prep1(c, p, B, true, s));
-    STAGE(ST_CONV_POOL, launch_conv_pool(c, p, B, s));
+    STAGE(ST_CONV_POOL, launch_conv_pool(c, p, B, true, s));
     }
     STAGE(ST_QMOM, launch_qmoments(c, B, s));
     STAGE(ST_PREP2, launch_prep2(c, p, B, true, s));

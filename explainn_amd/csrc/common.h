@@ -136,7 +136,7 @@ int launch_pack(explainn_ctx* c, const float* x, int B, bool counts, hipStream_t
 int launch_prep1(explainn_ctx* c, const explainn_params* p, int B, bool train, hipStream_t s);
 int launch_moments(explainn_ctx* c, int B, hipStream_t s);
 int launch_prep1_tables(explainn_ctx* c, const explainn_params* p, hipStream_t s);
-int launch_conv_pool(explainn_ctx* c, const explainn_params* p, int B, hipStream_t s);
+int launch_conv_pool(explainn_ctx* c, const explainn_params* p, int B, bool want_idx, hipStream_t s);
 int launch_pack_tables(explainn_ctx* c, const float* x, const explainn_params* p, int B, hipStream_t s);
 int launch_pack_codes(explainn_ctx* c, const uint8_t* codes, int B, int rc, hipStream_t s);
 int launch_conv_act(explainn_ctx* c, int B, float* acts, hipStream_t s);

@@ -50,7 +50,7 @@ template <int NU> struct fvec;
 template <> struct fvec<2> { typedef float type __attribute__((ext_vector_type(2))); };
 template <> struct fvec<4> { typedef float type __attribute__((ext_vector_type(4))); };
 
-template <int K, int NU, int CPW, typename Sink>
+template <int K, int NU, int CPW, bool IDX = true, typename Sink>
 __device__ __forceinline__ void conv_pool_windows(const void* L2, const void* Wp, uint32_t* pks,
                                                   uint32_t* nms, const uint32_t* __restrict__ pk2,
                                                   const uint32_t* __restrict__ nmask,
@@ -154,6 +154,8 @@ __device__ __forceinline__ void conv_pool_windows(const void* L2, const void* Wp
             ex[uu] = sg[uu] > 0.f ? hi : lo;
             bi[uu] = POOLW - 1;
         }
+        // (IDX = false -- eval: only the backward routes gradients by the argmax position)
+        if (IDX)
 #pragma unroll
         for (int i = POOLW - 2; i >= 0; --i) {
             bool eq[NU];
@@ -167,7 +169,7 @@ __device__ __forceinline__ void conv_pool_windows(const void* L2, const void* Wp
     }
 }
 
-template <int K, int CPW>
+template <int K, int CPW, bool IDX>
 __global__ __launch_bounds__(64) void conv_pool_kernel(const uint32_t* __restrict__ pk2,
                                                        const uint32_t* __restrict__ nmask,
                                                        const float4* __restrict__ lut,
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(64) void conv_pool_kernel(const uint32_t* __restric
     for (int uu = 0; uu < 4; ++uu) sg[uu] = (quad * 4 + uu < U && gamma1[quad * 4 + uu] < 0.f) ? -1.f : 1.f;
     __syncthreads();
     STAMP(1);
-    conv_pool_windows<K, 4, CPW>(L2, Wp, pks, nms, pk2, nmask, sg, b, lane, wbeg, wend, Bs, PW, NW,
+    conv_pool_windows<K, 4, CPW, IDX>(L2, Wp, pks, nms, pk2, nmask, sg, b, lane, wbeg, wend, Bs, PW, NW,
                             [&](int w, const float (&e)[4], const int (&i)[4]) {
                                 // wave-uniform row pointers + one 32-bit lane offset (saddr stores)
                                 const uint32_t o = (uint32_t)(w * Bs + b), o4 = o * 4u;
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(64) void conv_pool_kernel(const uint32_t* __restric
                                 for (int uu = 0; uu < 4; ++uu) {
                                     const size_t row = (size_t)(quad * 4 + uu) * n * Bs;
                                     *reinterpret_cast<float*>(reinterpret_cast<char*>(ext + row) + o4) = e[uu];
-                                    (idx + row)[o] = (uint8_t)i[uu];
+                                    if (IDX) (idx + row)[o] = (uint8_t)i[uu];
                                 }
                             });
     STAMP(2);
@@ -267,15 +269,21 @@ static size_t conv_pool_lds(const explainn_ctx* c, int cpw) {
     return (size_t)(NT * 16 + c->k * 5) * sizeof(float4) + (size_t)(pwc + nwc) * 64 * 4;
 }
 
-int launch_conv_pool(explainn_ctx* c, const explainn_params* p, int B, hipStream_t s) {
+int launch_conv_pool(explainn_ctx* c, const explainn_params* p, int B, bool want_idx, hipStream_t s) {
     const int wsplit = conv_pool_wsplit(c), cpw = conv_pool_cpw(c);
     const dim3 grid(((B + 63) / 64) * wsplit, c->Uq);
     const size_t sm = conv_pool_lds(c, cpw);
 #define ARGS grid, dim3(64), sm, s, c->pk2, c->nmask, reinterpret_cast<const float4*>(c->lut), c->Wt, \
              p->bn1_w, c->U, c->ext, c->idx, c->n, c->Bs, c->PW, c->NW, wsplit
+    // (the argmax offsets are the backward's: eval launches skip them -- 52 of ~260 instructions per window)
 #define CALL(KK)                                                                               \
-    if (cpw == 8) hipLaunchKernelGGL((conv_pool_kernel<KK, 8>), ARGS);                         \
-    else hipLaunchKernelGGL((conv_pool_kernel<KK, 32>), ARGS)
+    if (cpw == 8) {                                                                            \
+        if (want_idx) hipLaunchKernelGGL((conv_pool_kernel<KK, 8, true>), ARGS);               \
+        else hipLaunchKernelGGL((conv_pool_kernel<KK, 8, false>), ARGS);                       \
+    } else {                                                                                   \
+        if (want_idx) hipLaunchKernelGGL((conv_pool_kernel<KK, 32, true>), ARGS);              \
+        else hipLaunchKernelGGL((conv_pool_kernel<KK, 32, false>), ARGS);                      \
+    }
     K_DISPATCH(c->k, CALL);
 #undef CALL
 #undef ARGS
@@ -288,12 +296,17 @@ int conv_configure(explainn_ctx* c) {
     const size_t sm = conv_pool_lds(c, cpw);
     if (sm > 48 * 1024) {
 #define CALL(KK)                                                                               \
-        if (cpw == 8)                                                                          \
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pool_kernel<KK, 8>), \
+        if (cpw == 8) {                                                                        \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pool_kernel<KK, 8, true>), \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)); \
-        else                                                                                   \
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pool_kernel<KK, 32>), \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm))
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pool_kernel<KK, 8, false>), \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)); \
+        } else {                                                                               \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pool_kernel<KK, 32, true>), \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)); \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pool_kernel<KK, 32, false>), \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)); \
+        }
         K_DISPATCH(c->k, CALL);
 #undef CALL
     }
