@@ -5,7 +5,9 @@ import csv, glob, json, shutil, sys
 run, tag = sys.argv[1], sys.argv[2]
 S = "gpurun_out/" + run
 def cp(pattern, dst):
-    shutil.copy(glob.glob(S + "/" + pattern)[0], "profiles/%s_%s" % (tag, dst))
+    # the newest match: gpurun merges every call's files into the same local directory
+    import os
+    shutil.copy(max(glob.glob(S + "/" + pattern), key=os.path.getmtime), "profiles/%s_%s" % (tag, dst))
 cp("bench.json", "bench.json"); cp("stats/*/*kernel_stats.csv", "kernel_stats.csv")
 cp("kernel_summary.txt", "kernel_summary.txt")
 for p, name in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE"), ("sq1", "SQ1"), ("sq2", "SQ2")):
