@@ -142,7 +142,7 @@ int main() {
         size_t cps = (size_t)(NT * 16 + k * 5) * 16 + (size_t)(8 + 5) * 64 * 4;   // 8-window code tiles (convpool.hip: conv_pool_lds)
         for (int rep = 0; rep < 2; ++rep) {
             CK(hipEventRecord(e0));
-            hipLaunchKernelGGL((conv_pool_kernel<19, 8>), dim3(16 * 4, U4 / 4), dim3(64), cps, 0, pk2, nmask, (const float4*)lut, Wt, alpha, U, ext, idx, n, Bs, PW, NW, 4);
+            hipLaunchKernelGGL((conv_pool_kernel<19, 8, true>), dim3(16 * 4, U4 / 4), dim3(64), cps, 0, pk2, nmask, (const float4*)lut, Wt, alpha, U, ext, idx, n, Bs, PW, NW, 4);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
             if (rep) report("conv_pool", 16 * 4 * (U4 / 4), 3, ms);
             CK(hipEventRecord(e0));
