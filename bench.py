@@ -165,9 +165,10 @@ def kernel_model(w, B):
     nt = (K + 1) // 2
     return {
         # FLOPs of the UNPADDED problem (100 hidden channels, n pooled positions), priced against
-        # the fp32 MFMA peak.  fc_fwd runs on the exact-fp32 MFMA; passA and the T.bit part of passB
-        # have a bit matrix as one operand and run on the bf16 MFMA with the real operand split
-        # exactly into three bf16 pieces (fp32-equivalent result, 3/16 of the fp32 cost), so their
+        # the fp32 MFMA peak ("mfma_f32" = the yardstick, not the instruction).  The contractions run
+        # on the bf16 MFMA with fp32 operands split exactly into three bf16 pieces: passA and the T.bit
+        # part of passB have a bit matrix as one operand (3 piece products, 3/16 of the fp32 cost),
+        # fc_fwd has two real operands (9 piece products, 9/16) -- fp32-equivalent results, so the
         # fraction of the fp32 peak may exceed what an fp32-MFMA kernel could reach
         "fc_fwd": ("mfma_f32", 2.0 * 100 * n * B * U),
         "passA": ("mfma_f32", 2.0 * 100 * n * B * U),
