@@ -8,7 +8,10 @@ train-mode forward (dropout 0.3 active) + BCE-with-logits loss + backward into a
 buffer, plus -- for N > 1 -- one RCCL all-reduce of that buffer.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C2|C3|C4|C5] [--scaling weak|strong]
-  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`)
+  N > 1 runs one process per GPU over RCCL: either launched by the driver as
+  `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`, or -- when WORLD_SIZE is
+  not set -- by this script itself: the parent (which never touches the GPU) starts that very command
+  as a child process, relays rank 0's JSON line and exits with the child's status.
 
 --scaling weak (default): every GPU takes the workload's per-GPU batch.  --scaling strong: the
 workload's GLOBAL batch (C4: 8192 x 1000 bp x 50 tasks) is split over the N ranks.
@@ -25,8 +28,6 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-
-import torch  # noqa: E402
 
 K = 19
 # BASELINE.json configs[1..4]: units, length, tasks, per-GPU batch of the
@@ -45,6 +46,42 @@ HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s 
 MFMA_F32_PEAK_TFLOPS = 157.3      # same guide: fp32 MFMA = fp32 vector rate
 LDS_PEAK_GBPS = 150000.0          # ds_read_b64/b128 aggregate
 CLOCK_HZ, SIMDS = 2.4e9, 1024
+
+
+def launcher_command(argv, gpus, port=None, python=None):
+    """The command a plain `python bench.py --gpus N` re-issues itself as: one rank per GPU of this
+    node under torch.distributed.run, rendezvous on 127.0.0.1 (the container's hostname may not
+    resolve).  `argv` = this script's own arguments, passed through unchanged."""
+    if port is None:
+        port = 29500 + (os.getpid() % 2000)
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+            "--nproc-per-node", str(int(gpus)), "--master-addr", "127.0.0.1",
+            "--master-port", str(int(port)), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(argv, gpus):
+    """Parent of a multi-GPU run started without a launcher.  Nothing here initialises HIP (no torch
+    import, no device query): the ranks are CHILD processes, never an exec of a process that has
+    touched the GPU.  Rank 0's JSON line is the only thing written to stdout."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it here
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = launcher_command(argv, gpus)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for raw in proc.stdout:
+        if raw.startswith("{") and '"metric"' in raw:
+            line = raw.strip()
+        else:
+            sys.stderr.write(raw)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks exited without a result line\n")
+        rc = 1
+    return rc
 
 
 def algorithmic_bytes_per_step(B, L, T, P):
@@ -197,6 +234,11 @@ def main():
     ap.add_argument("--skip-stage-times", action="store_true",
                     help="skip the per-kernel HIP-event leg (profiling runs)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher (before torch is even imported)
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus))
+    global torch
+    import torch
     w = WORKLOADS[args.workload]
     U, L, T = w["U"], w["L"], w["T"]
 
@@ -246,7 +288,7 @@ def main():
     P = eng.flat_grad.numel()
     x, y = synthetic_batch(B, L, T, 1000 + rank, dev, args.n_frac)
 
-    def one_step(i):
+    def one_step(i, overlap=overlap):
         if overlap:
             eng.step(x, y, seed=(rank << 40) + i + 1, grad_sync=sync)
         else:
@@ -259,18 +301,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        one_step(i)
-    fence()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for i in range(args.steps):
-        one_step(args.warmup + i)
-    ev1.record()
-    fence()
-    wall = time.perf_counter() - t0
-    gpu_ms = ev0.elapsed_time(ev1)       # HIP events on the launch stream (torch current stream)
+    def timed_region(ov):
+        """W untimed + exactly K timed steps between barrier + synchronize fences; host wall time
+        and the HIP-event time on the launch stream."""
+        for i in range(args.warmup):
+            one_step(i, ov)
+        fence()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t_start = time.perf_counter()
+        e0.record()
+        for i in range(args.steps):
+            one_step(args.warmup + i, ov)
+        e1.record()
+        fence()
+        return time.perf_counter() - t_start, e0.elapsed_time(e1)
+
+    wall, gpu_ms = timed_region(overlap)
+    # N > 1: the other all-reduce schedule is timed as well (same K steps, after the headline
+    # region) so that the choice between them rests on data from the node that ran this
+    wall_alt = 0.0
+    if sync is not None:
+        wall_alt, _ = timed_region(not overlap)
     # secondary figure (SURVEY.md 8d: "report with and without the optimiser step"): the same step
     # followed by the fused Adam update, timed the same way; not part of `value`
     wall_opt = 0.0
@@ -307,10 +358,12 @@ def main():
     assert flags == 0, "synthetic input flagged as not one-hot"
     assert torch.isfinite(eng.loss).all() and torch.isfinite(eng.flat_grad).all()
 
-    t = torch.tensor([wall, wall_opt], device=dev, dtype=torch.float64)
+    t = torch.tensor([wall, wall_opt, wall_alt], device=dev, dtype=torch.float64)
+    n_ranks_seen = 1
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall, wall_opt = float(t[0].item()), float(t[1].item())
+        n_ranks_seen = dist.get_world_size()
+    wall, wall_opt, wall_alt = float(t[0].item()), float(t[1].item()), float(t[2].item())
     if rank == 0:
         seqs = B * world * args.steps
         step_gpu_s = gpu_ms / 1e3 / args.steps
@@ -351,6 +404,7 @@ def main():
         out = {
             "metric": metric,
             "value": round(seqs / wall, 1), "unit": "sequences/s", "n_gpus": world,
+            "n_ranks_seen": n_ranks_seen,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -390,6 +444,16 @@ def main():
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
+        if dist is not None:
+            names = ("one all-reduce of the flat gradient after the step",
+                     "FC/head gradients reduced under the filter-bank backward + a second reduce of the rest")
+            out["allreduce"] = {
+                "backend": "nccl (RCCL)", "bytes": 4 * P,
+                "schedule": names[1 if overlap else 0], "ms_per_step": round(wall / args.steps * 1e3, 4),
+                "other_schedule": names[0 if overlap else 1],
+                "other_ms_per_step": round(wall_alt / args.steps * 1e3, 4),
+                "select": "EXPLAINN_BENCH_OVERLAP=0|1",
+                "rccl_debug": "run with NCCL_DEBUG=INFO to see the algorithm / protocol RCCL picked"}
         if args.n_frac > 0:
             out["data"] = "synthetic, %.3g N bases" % args.n_frac
         print(json.dumps(out), flush=True)

@@ -47,7 +47,10 @@ def codes_from_strings(seqs):
 
 def read_tsv_codes(tsv_file, debugging=False):
     """train.py:266-284 without the one-hot: headerless TSV `id <tab> sequence <tab> y0 [...]`
-    -> (codes (N,L) uint8, labels (N,T) float32, ids)."""
+    -> (codes (N,L) uint8, labels (N,T) float32, ids).  debugging=True keeps the first 1000 rows:
+    the reference's cut (train.py:280-282) comes AFTER its reverse-complement doubling, and item i
+    of the doubled set is row i for i < N, so the first 1000 rows are all a debugging run can reach
+    -- `CodesLoader(limit=1000)` applies the cut itself on the doubled range."""
     import pandas as pd
     df = pd.read_csv(tsv_file, sep="\t", header=None)
     if debugging:
@@ -97,10 +100,16 @@ class CodesLoader:
     twice as long, item N+i being the reverse complement of item i with the same target
     (train.py:275-278), generated per batch.  With `device` set, batches arrive on that device:
     gathered into one of `depth` pinned staging buffers, copied on a side stream while the
-    previous batch is being consumed, and handed over after a stream-wait (no host sync)."""
+    previous batch is being consumed, and handed over after a stream-wait (no host sync).
+    `limit` truncates the LOGICAL data set after the reverse-complement doubling (train.py:280-282
+    `--debugging`: `seqs[:1000]` of the doubled array).
+
+    Device batches are views into a ring of `depth` staging slots: a yielded pair is valid until
+    the next `next()` on the iterator (the slot is refilled two iterations later); a consumer
+    that keeps batches must clone them."""
 
     def __init__(self, codes, labels, batch_size=100, shuffle=False, reverse_complement=False,
-                 device=None, depth=3):
+                 device=None, depth=3, limit=None):
         self.codes = np.ascontiguousarray(codes, dtype=np.uint8)
         self.labels = np.ascontiguousarray(labels, dtype=np.float32)
         if self.labels.ndim == 1:
@@ -109,8 +118,10 @@ class CodesLoader:
             raise ValueError("codes and labels differ in length")
         self.n_base = len(self.codes)
         self.rc = bool(reverse_complement)
-        self.dataset = range(self.n_base * (2 if self.rc else 1))
-        n = len(self.dataset)
+        n = self.n_base * (2 if self.rc else 1)
+        if limit is not None:
+            n = min(n, int(limit))
+        self.dataset = range(n)
         # train.py:297-302: never leave a last batch of one sample (BatchNorm raises on it)
         while batch_size > 1 and n % batch_size == 1:
             batch_size -= 1
@@ -180,6 +191,12 @@ class CodesLoader:
         batches = iter(self._sampler())
         pending = []                            # (slot index, batch length), staged ahead
         k = 0
+        # An earlier iterator may have been abandoned mid-epoch with a slot still being read by
+        # work on the consumer's stream and no `free` event recorded for it: order every copy of
+        # this iterator after whatever the consumer has enqueued so far.
+        self._stream.wait_stream(torch.cuda.current_stream(self.device))
+        for slot in self._slots:
+            slot["free"] = torch.cuda.Event()    # an unrecorded event: synchronize() returns at once
         for _ in range(self.depth - 1):
             idx = next(batches, None)
             if idx is None:
@@ -191,9 +208,12 @@ class CodesLoader:
             slot = self._slots[si]
             cur = torch.cuda.current_stream(self.device)
             cur.wait_event(slot["ready"])
-            yield slot["dc"][:b], slot["dy"][:b]
-            # whatever the consumer enqueued on the current stream reads the slot: mark its end
-            slot["free"].record(torch.cuda.current_stream(self.device))
+            try:
+                yield slot["dc"][:b], slot["dy"][:b]
+            finally:
+                # whatever the consumer enqueued on the current stream reads the slot: mark its end
+                # (also when the generator is closed or collected instead of resumed)
+                slot["free"].record(torch.cuda.current_stream(self.device))
             idx = next(batches, None)
             if idx is not None:
                 pending.append((k % self.depth, self._stage(self._slots[k % self.depth], idx)))

@@ -227,7 +227,9 @@ class Trainer(object):
         self.model.eval()
         batch_losses, all_predictions, all_targets = [], [], []
         for inputs, targets in iter(self.data_loaders[which_data]):
-            all_targets.append(targets.data.cpu().numpy())       # already on the host: no round trip
+            # a device-resident loader (loader.CodesLoader) yields views of a staging ring: cloned
+            # on the device and brought to the host ONCE after the loop; host batches are kept as is
+            all_targets.append(targets.data.clone() if targets.is_cuda else targets.data)
             if self.use_cuda:
                 inputs = inputs.cuda()
                 targets = targets.cuda()
@@ -239,7 +241,8 @@ class Trainer(object):
                 all_predictions.append(predictions.data)
         losses = torch.cat(batch_losses).tolist() if batch_losses else []
         preds = torch.cat(all_predictions).cpu().numpy() if all_predictions else np.zeros((0, 0))
-        return (np.average(losses), preds, np.vstack(all_targets))
+        tgts = torch.cat(all_targets).cpu().numpy() if all_targets else np.zeros((0, 0))
+        return (np.average(losses), preds, tgts)
 
     def validate(self):
         """Validation metrics on flattened predictions; best model -> best_model.pth.tar

@@ -13,6 +13,31 @@ GOLDEN_CASES = ["tiny_u1_k5", "tiny_u3_k5_N", "small_u8_k19", "small_u8_k19_mse"
                 "tandem_u3_k5", "mid_u8_k19_L200", "c1_u100_k19_L200"]
 
 
+_MARGINS = {}
+
+
+def record_margin(what, err_over_scale, tol):
+    """Remember the worst error/bound ratio seen per comparison label; written at session end to
+    gpurun_out/parity_margins.txt (the evidence for how much headroom each tolerance has)."""
+    cur = _MARGINS.get(what)
+    if cur is None or err_over_scale / tol > cur[0] / cur[1]:
+        _MARGINS[what] = (float(err_over_scale), float(tol))
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _MARGINS:
+        return
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_margins.txt"), "w") as f:
+            f.write("# worst error (relative to the comparison's scale) per label, its bound, and the ratio\n")
+            for what, (e, t) in sorted(_MARGINS.items(), key=lambda kv: -kv[1][0] / kv[1][1]):
+                f.write("%-70s err %.3e  bound %.1e  used %.3f\n" % (what, e, t, e / t))
+    except OSError:
+        pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

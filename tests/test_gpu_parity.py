@@ -1,15 +1,18 @@
 """Parity of the HIP path (through the C ABI, via the drop-in module) against the golden vectors
 the imported reference produced and against the numpy oracle.  Needs an MI355X: -m gpu.
 
-Tolerance: 1e-4 absolute on logits / relative-to-max on gradients (BASELINE.json north_star:
-"within 1e-4 fp32").  Tensors with identically-zero true gradient (pre-BatchNorm biases) are
-checked with an absolute bound only."""
+Tolerance: 1e-4 absolute on logits (BASELINE.json north_star: "within 1e-4 fp32"); gradients and
+BatchNorm buffers RELATIVE to the largest entry of the reference tensor: 2e-5 against the
+reference's own numbers (golden fixtures), 5e-5 against the fp64 oracle on random cases.  Tensors
+with identically-zero true gradient (pre-BatchNorm biases) are checked with an absolute bound only
+(SURVEY.md 7.2).  Every comparison's error/bound ratio is appended to gpurun_out/parity_margins.txt
+(conftest.record_margin) so the headroom of each bound is on record."""
 import numpy as np
 import pytest
 
 torch = pytest.importorskip("torch")
 
-from conftest import Golden  # noqa: E402
+from conftest import Golden, record_margin  # noqa: E402
 from oracle import explainn_oracle as orc  # noqa: E402
 
 pytestmark = pytest.mark.gpu
@@ -18,13 +21,32 @@ TOL = 1e-4
 ZERO_GRAD = ("linears.0.bias", "linears.6.bias", "linears.10.bias")
 
 
+GRAD_TOL_GOLDEN = 2e-5     # gradients / BatchNorm buffers vs the reference's own numbers, relative to max|ref|
+GRAD_TOL_ORACLE = 5e-5     # the same vs the fp64 numpy oracle on random cases
+
+
 def _close(a, b, tol=TOL, what=""):
+    """Absolute bound (logits, losses, predictions: north_star's "within 1e-4 fp32")."""
     a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
     assert a.shape == b.shape, (what, a.shape, b.shape)
     assert np.isfinite(a).all(), what + ": non-finite values"
     err = np.abs(a - b).max() if a.size else 0.0
     scale = max(1.0, np.abs(b).max() if b.size else 1.0)
+    record_margin("abs " + what, err / scale, tol)
     assert err <= tol * scale, "%s: max|d|=%.3e (scale %.3g)" % (what, err, scale)
+
+
+def _close_rel(a, b, tol=GRAD_TOL_GOLDEN, what=""):
+    """Relative to max|ref| of the tensor itself (gradients and buffers: a tensor whose entries
+    are all of order 1e-3 must agree to tol of THAT, not of 1.0)."""
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert np.isfinite(a).all(), what + ": non-finite values"
+    err = np.abs(a - b).max() if a.size else 0.0
+    scale = max(1e-12, np.abs(b).max() if b.size else 1.0)
+    record_margin("rel " + what, err / scale, tol)
+    assert err <= tol * scale, "%s: max|d|=%.3e = %.3e of max|ref| %.3g (bound %.1e)" % (
+        what, err, err / scale, scale, tol)
 
 
 def _model(sd, U, k, L, T):
@@ -97,16 +119,16 @@ def test_train_forward_backward_golden(golden):
         if k in ZERO_GRAD:
             assert np.abs(got).max() < 1e-6, k
         else:
-            _close(got, v, what="grad " + k)
+            _close_rel(got, v, what="grad " + k)
     if "train0/grad_rows/linears.6.weight" in g.z.files:
-        _close(_np(params["linears.6.weight"].grad)[:200], g.z["train0/grad_rows/linears.6.weight"],
-               what="grad rows linears.6.weight")
+        _close_rel(_np(params["linears.6.weight"].grad)[:200], g.z["train0/grad_rows/linears.6.weight"],
+                   what="grad rows linears.6.weight")
     bufs = dict(m.named_buffers())
     for k, v in g.group("train0/buf/").items():
         if "tracked" in k:
             assert int(bufs[k].item()) == int(v), k
         else:
-            _close(_np(bufs[k]), v, what="buffer " + k)
+            _close_rel(_np(bufs[k]), v, what="buffer " + k)
 
 
 def test_train_with_reference_dropout_mask(golden):
@@ -116,7 +138,7 @@ def test_train_with_reference_dropout_mask(golden):
     _close(loss.item(), g.z["drop/loss"], tol=1e-5, what="loss")
     params = dict(m.named_parameters())
     for k, v in g.group("drop/grad/").items():
-        _close(_np(params[k].grad), v, what="grad " + k)
+        _close_rel(_np(params[k].grad), v, what="grad " + k)
 
 
 def test_adam_trajectory_golden(golden):
@@ -229,11 +251,11 @@ def test_train_step_vs_oracle(U, k, L, T, B, nfrac):
         if key in ZERO_GRAD:
             assert np.abs(got).max() < 1e-6, key
         else:
-            _close(got.reshape(v.shape), v, tol=2e-4, what="grad " + key)
+            _close_rel(got.reshape(v.shape), v, tol=GRAD_TOL_ORACLE, what="grad " + key)
     bufs = dict(m.named_buffers())
     for key, v in nb.items():
         if "tracked" not in key:
-            _close(_np(bufs[key]), v, what=key)
+            _close_rel(_np(bufs[key]), v, tol=GRAD_TOL_ORACLE, what=key)
     # eval mode from the updated buffers
     m.eval()
     sd2 = dict(sd); sd2.update(nb)
@@ -253,7 +275,7 @@ def _check_grads(named, ref_grads, what=""):
         if key in ZERO_GRAD:
             assert np.abs(_np(got)).max() < 1e-6, key
         else:
-            _close(_np(got).reshape(v.shape), v, tol=2e-4, what="%sgrad %s" % (what, key))
+            _close_rel(_np(got).reshape(v.shape), v, tol=GRAD_TOL_ORACLE, what="%sgrad %s" % (what, key))
 
 
 @pytest.mark.parametrize("freeze", [1, 3, 5])
@@ -313,7 +335,7 @@ def test_large_context_small_batch_vs_oracle():
     bufs = dict(m.named_buffers())
     for key, v in nb.items():
         if "tracked" not in key:
-            _close(_np(bufs[key]), v, what=key)
+            _close_rel(_np(bufs[key]), v, tol=GRAD_TOL_ORACLE, what=key)
 
 
 def test_eval_forward_invalidates_a_pending_backward():
@@ -398,7 +420,7 @@ def test_soft_input_takes_the_dense_path():
     bufs = dict(m.named_buffers())
     for key, v in nb.items():
         if "tracked" not in key:
-            _close(_np(bufs[key]), v, what=key)
+            _close_rel(_np(bufs[key]), v, tol=GRAD_TOL_ORACLE, what=key)
     # dense_input=True sends a ONE-HOT batch down the dense kernels too: same numbers as the fast path
     m2 = _model(sd, U, k, L, T).eval()
     m2.dense_input = True
@@ -458,7 +480,7 @@ def test_step_engine_vs_oracle(T, kind):
         if key in ZERO_GRAD:
             assert np.abs(_np(v)).max() < 1e-6, key
         else:
-            _close(_np(v).reshape(ref_grads[key].shape), ref_grads[key], tol=2e-4, what="grad " + key)
+            _close_rel(_np(v).reshape(ref_grads[key].shape), ref_grads[key], tol=GRAD_TOL_ORACLE, what="grad " + key)
 
 
 # ---- base-code input: same numbers as the fp32 one-hot, bit for bit ------------
@@ -632,7 +654,7 @@ def test_smaller_batch_after_larger_one_on_the_same_context():
         if key in ZERO_GRAD:
             assert np.abs(_np(v)).max() < 1e-6, key
         else:
-            _close(_np(v).reshape(ref_grads[key].shape), ref_grads[key], tol=2e-4, what="grad " + key)
+            _close_rel(_np(v).reshape(ref_grads[key].shape), ref_grads[key], tol=GRAD_TOL_ORACLE, what="grad " + key)
 
 
 def test_graph_replay_equals_direct_launches():

@@ -378,3 +378,49 @@ def test_trainer_from_codes_equals_trainer_from_one_hot(tmp_path):
     assert res[0][0] == res[1][0] and res[0][1] == res[1][1]
     for key in res[0][2]:
         assert torch.equal(res[0][2][key], res[1][2][key]), key
+
+
+@pytest.mark.parametrize("gz", [False, True])
+def test_filter_weights_pickle_as_the_reference_writes_it(tmp_path, gz):
+    """interpret.py:154-163 pickles `{(name, 'filterN'): filter_w.T}` with HIGHEST_PROTOCOL
+    (protocol 5 goes through numpy's _frombuffer for contiguous and Fortran-order arrays);
+    train.py:183-195 reads it back.  The allow-listed unpickler must accept exactly that and still
+    refuse anything that is not an array container."""
+    import gzip
+    import pickle
+    from explainn_amd.train import _load_filter_weights
+    rng = np.random.default_rng(0)
+    filters = [rng.standard_normal((4, 19)).astype(np.float32) for _ in range(3)]
+    obj = {("model.pth.tar", "filter%d" % i): w.T for i, w in enumerate(filters)}      # (k,4), F-order views
+    obj[("model.pth.tar", "filter3")] = np.ascontiguousarray(filters[0].T)             # C-order too
+    path = str(tmp_path / ("weights.pkl" + (".gz" if gz else "")))
+    with (gzip.open(path, "wb") if gz else open(path, "wb")) as fh:
+        pickle.dump(obj, fh, protocol=pickle.HIGHEST_PROTOCOL)
+    ids, ws = _load_filter_weights(path)
+    assert ids == ["model.pth.tar;filter%d" % i for i in range(4)]
+    for w, ref in zip(ws, filters + [filters[0]]):
+        assert tuple(w.shape) == (4, 19) and np.array_equal(w.numpy(), ref)
+    bad = str(tmp_path / "bad.pkl")
+    with open(bad, "wb") as fh:
+        pickle.dump({"a": os.system}, fh, protocol=pickle.HIGHEST_PROTOCOL)
+    with pytest.raises(pickle.UnpicklingError):
+        _load_filter_weights(bad)
+
+
+def test_debugging_cut_comes_after_the_reverse_complement_doubling():
+    """train.py:272-282: `--debugging` keeps `seqs[:1000]` of the ALREADY doubled array, i.e. 1000
+    items (forward sequences first), not 1000 rows doubled to 2000."""
+    from explainn_amd.loader import CodesLoader
+    rng = np.random.default_rng(3)
+    for n_rows in (1200, 600):
+        codes = rng.integers(0, 4, (n_rows, 30)).astype(np.uint8)
+        labels = np.arange(n_rows, dtype=np.float32)[:, None]
+        # what the reference builds: forward rows, then their reverse complements, then the cut
+        doubled = np.concatenate([codes, (3 - codes)[:, ::-1]])[:1000]
+        doubled_y = np.concatenate([labels, labels])[:1000]
+        loader = CodesLoader(codes[:1000], labels[:1000], batch_size=100, shuffle=False,
+                             reverse_complement=True, limit=1000)
+        assert len(loader.dataset) == 1000 and len(loader) == 10
+        got_c = np.concatenate([c.numpy() for c, _ in loader])
+        got_y = np.concatenate([y.numpy() for _, y in loader])
+        assert np.array_equal(got_c, doubled) and np.array_equal(got_y, doubled_y)
