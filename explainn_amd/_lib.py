@@ -49,6 +49,7 @@ EXPORTS = (
     "explainn_train_step_fc", "explainn_train_step_conv",
     "explainn_stage_onehot", "explainn_dense_input",
     "explainn_stage_timing", "explainn_stage_count", "explainn_stage_name", "explainn_stage_times",
+    "explainn_debug_keep_bits",
 )
 
 
@@ -131,6 +132,8 @@ def load():
     lib.explainn_stage_name.restype = C.c_char_p
     lib.explainn_stage_times.argtypes = [ctx, C.POINTER(C.c_float), C.c_int]
     lib.explainn_stage_times.restype = C.c_int
+    lib.explainn_debug_keep_bits.argtypes = [ctx, C.c_int, _fp, _fp]
+    lib.explainn_debug_keep_bits.restype = C.c_int
     lib.explainn_input_flags.argtypes = [ctx, C.POINTER(C.c_int), _fp]
     lib.explainn_input_flags.restype = C.c_int
     _lib = lib

@@ -14,6 +14,7 @@ The compute is in libexplainn_hip.so (include/explainn_hip.h); PyTorch only owns
 memory, the stream and autograd bookkeeping.  There is no CPU or eager fallback: a model that is
 not on a HIP device raises.
 """
+import contextlib
 import copy
 import ctypes as C
 import math
@@ -137,6 +138,9 @@ class BaseCodes:
         return self.codes.shape
 
 
+VALIDATE_EVERY = 64      # deferred input validation: the sticky device flag is read every this many calls
+
+
 class _Runtime:
     """Per-model device context; never copied or pickled with the module."""
 
@@ -145,6 +149,9 @@ class _Runtime:
         self.token = 0
         self.pending = None
         self.x_keep = None
+        self.calls = 0           # forwards since the model was built (input validation schedule)
+        self.soft_seen = False   # a validating call met a batch that was not one-hot
+        self.cache_depth = 0     # nesting depth of eval_cache() scopes
 
     def __deepcopy__(self, memo):
         return _Runtime()
@@ -227,6 +234,13 @@ class ExplaiNN(_Model):
         self.linears._bind(self)
         self.final = nn.Linear(U, n_features)
         self.dropout_p = DROPOUT_P
+        # Input validation (is every column of x one-hot or all-zero?) happens on the device while
+        # the batch is packed and raises a sticky flag.  True: the first two forwards read the flag
+        # before computing (so that a soft batch is routed to the dense kernels), later ones
+        # enqueue and return without touching the host; the flag is then read every
+        # VALIDATE_EVERY-th call, by check_input(), and at the end of predict() / a validation pass.
+        # "always": every call validates before computing (one host sync per forward).
+        # False: never.
         self.validate_input = True
         # None: a batch that fails validation takes the dense kernels (the reference accepts any
         # float input); True: always dense; False: a batch that is not one-hot is an error
@@ -348,15 +362,43 @@ class ExplaiNN(_Model):
         return ps, keep
 
     def _stamp_version(self, ps, keep):
-        """explainn_params.version: a counter that moves whenever any of the 23 tensors changed
-        value (torch's per-tensor version counters; this package's own kernels, which write
-        through raw pointers, bump them explicitly -- _touched()).  The eval entry points rebuild
-        their folded tables only when it moved."""
+        """explainn_params.version: 0 ("unknown": the eval entry points rebuild their folded
+        tables on every call) unless an eval_cache() scope is open; inside one, a counter that
+        moves whenever any of the 23 tensors changed value as far as torch can tell (its per-tensor
+        version counters; this package's own kernels, which write through raw pointers, bump
+        them explicitly -- _touched()).  Writes through `.data` do NOT move torch's counters
+        (`p.data.clamp_(0)`, selene/__init__.py:294), which is why caching is opt-in and scoped:
+        the scope's owner promises not to do that inside it, or calls invalidate()."""
+        if self._rt.cache_depth <= 0:
+            ps.version = 0
+            return
         vkey = tuple(t._version for t in keep)
         if vkey != self.__dict__.get("_vkey"):
             self.__dict__["_vkey"] = vkey
             self.__dict__["_pver"] = self.__dict__.get("_pver", 0) + 1
         ps.version = self.__dict__["_pver"]
+
+    def invalidate(self):
+        """Forget the cached eval-mode tables (after writing parameters or buffers through `.data`
+        or raw pointers inside an eval_cache() scope)."""
+        self.__dict__["_pver"] = self.__dict__.get("_pver", 0) + 1
+        self.__dict__.pop("_vkey", None)
+
+    @contextlib.contextmanager
+    def eval_cache(self):
+        """Scope in which eval-mode forwards reuse the folded tables (filter LUTs, BatchNorm folds,
+        FC1 fragments) of the previous call instead of rebuilding them per batch -- predict(), a
+        validation pass and the filter export open one around their loops.  Contract: inside the
+        scope parameters and buffers change only through torch ops that bump tensor versions
+        (optimiser steps, in-place ops on the tensor itself, load_state_dict, re-assignment) or
+        through this package's kernels; after a `.data` write call invalidate()."""
+        self._rt.cache_depth += 1
+        if self._rt.cache_depth == 1:
+            self.invalidate()            # whatever happened outside the scope is unknown
+        try:
+            yield self
+        finally:
+            self._rt.cache_depth -= 1
 
     def _touched(self):
         """The train-mode kernels updated the BatchNorm buffers in place (as torch does)."""
@@ -380,14 +422,25 @@ class ExplaiNN(_Model):
             raise RuntimeError("input is on %s but the model is on %s" % (x.device, dev))
         return x.detach().to(torch.float32).contiguous()
 
+    def _validate_now(self):
+        """Does THIS forward read the validation flag before computing?  (validate_input above.)"""
+        v = self.validate_input
+        if not v:
+            return False
+        # a model that has met a soft batch once keeps validating (and routing) per call
+        return v == "always" or self._rt.soft_seen or self._rt.calls <= 2
+
     def _x_ptr(self, ctx, x, dev, validate=None):
         """Device pointer of the batch as the C ABI wants it: base codes are staged in the context
         and NULL ("the staged batch", include/explainn_hip.h) is returned.  An fp32 batch is, when
-        input validation is on, staged too and its validation flag read BEFORE anything is
-        computed from it: a batch that is not one-hot (the reference accepts any float tensor,
-        architectures/__init__.py:111) goes through the dense kernels instead of being run as if
-        its soft columns were N -- unless dense_input is False, which keeps the strict error."""
+        this call validates (validate_input), staged too and its validation flag read BEFORE
+        anything is computed from it: a batch that is not one-hot (the reference accepts any float
+        tensor, architectures/__init__.py:111) goes through the dense kernels instead of being
+        run as if its soft columns were N -- unless dense_input is False, which keeps the strict
+        error.  Otherwise the batch is packed inside the forward itself and the flag stays sticky
+        on the device for a later read (no host sync in the call)."""
         lib, h, stream = ctx.lib, ctx.handle, self._stream(dev)
+        self._rt.calls += 1
         if isinstance(x, BaseCodes):
             _lib.check(lib.explainn_dense_input(h, 0))
             _lib.check(lib.explainn_stage_codes(h, x.codes.data_ptr(), x.codes.shape[0],
@@ -397,11 +450,12 @@ class ExplaiNN(_Model):
             _lib.check(lib.explainn_dense_input(h, 1))
             self._rt.x_keep = x
             return x.data_ptr()
-        if self.validate_input if validate is None else validate:
+        if self._validate_now() if validate is None else validate:
             _lib.check(lib.explainn_stage_onehot(h, x.data_ptr(), x.shape[0], stream))
             flags = C.c_int(0)
             _lib.check(lib.explainn_input_flags(h, C.byref(flags), stream))
             if flags.value & 1:
+                self._rt.soft_seen = True
                 if self.dense_input is False:
                     raise ValueError(
                         "input is not one-hot: every column of x must be one-hot (A,C,G,T) or all-zero "
@@ -417,15 +471,31 @@ class ExplaiNN(_Model):
     def _stream(self, dev):
         return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
-    def _check_flags(self, ctx, dev):
+    def _check_flags(self, ctx, dev, x=None):
+        """After a forward was enqueued: read the sticky flag when this call is one that reads it
+        (a validating call already did for an fp32 batch -- base codes are only checked here -- and
+        every VALIDATE_EVERY-th call settles the deferred ones)."""
         if not self.validate_input:
             return
-        flags = C.c_int(0)
-        _lib.check(ctx.lib.explainn_input_flags(ctx.handle, C.byref(flags), self._stream(dev)))
-        if flags.value & 1:
+        codes = isinstance(x, BaseCodes)
+        if self.dense_input and not codes:
+            return                                    # dense kernels: nothing is packed or flagged
+        now = self._validate_now()
+        if now and not codes:
+            return                                    # _x_ptr read (and cleared) the flag already
+        if now or self._rt.calls % VALIDATE_EVERY == 0:
+            self.check_input()
+
+    def check_input(self):
+        """Read (one host sync) and clear the sticky validation flag; raise if any batch since the
+        last read was not one-hot.  predict(), Trainer validation passes and the filter export call
+        it after their loops."""
+        if self.input_flags() & 1:
             raise ValueError(
                 "input is not one-hot: base codes must be 0..4, and every column of an fp32 x must "
-                "be one-hot (A,C,G,T) or all-zero (N) as sequence.one_hot_encode produces")
+                "be one-hot (A,C,G,T) or all-zero (N) as sequence.one_hot_encode produces.  A batch "
+                "since the last check was run with such columns read as N; for soft (real-valued) "
+                "input set model.dense_input = True, or validate_input = 'always' to route per batch")
 
     def input_flags(self):
         """Synchronise and return (then clear) the device-side input validation flags."""
@@ -456,7 +526,7 @@ class ExplaiNN(_Model):
         with torch.cuda.device(dev):
             _lib.check(ctx.lib.explainn_forward_eval(ctx.handle, self._x_ptr(ctx, x, dev), B, C.byref(ps),
                                                      logits.data_ptr(), self._stream(dev)))
-            self._check_flags(ctx, dev)
+            self._check_flags(ctx, dev, x)
         return logits
 
     def _launch_train(self, x, keep_mask=None):
@@ -483,7 +553,7 @@ class ExplaiNN(_Model):
             _lib.check(ctx.lib.explainn_forward_train(
                 ctx.handle, self._x_ptr(ctx, x, dev), B, C.byref(ps), mask_ptr, float(self.dropout_p),
                 C.c_uint64(seed), logits.data_ptr(), self._stream(dev)))
-            self._check_flags(ctx, dev)
+            self._check_flags(ctx, dev, x)
         self._touched()
         self._rt.token += 1
         return logits, self._rt.token
@@ -542,7 +612,7 @@ class ExplaiNN(_Model):
         with torch.cuda.device(dev):
             _lib.check(ctx.lib.explainn_unit_outputs(ctx.handle, self._x_ptr(ctx, x, dev), B, C.byref(ps),
                                                      outs.data_ptr(), self._stream(dev)))
-            self._check_flags(ctx, dev)
+            self._check_flags(ctx, dev, x)
         return outs
 
     def _unit_activations(self, x_rep):
@@ -561,7 +631,7 @@ class ExplaiNN(_Model):
         with torch.cuda.device(dev):
             _lib.check(ctx.lib.explainn_unit_activations(ctx.handle, self._x_ptr(ctx, x, dev), B, C.byref(ps),
                                                          acts.data_ptr(), self._stream(dev)))
-            self._check_flags(ctx, dev)
+            self._check_flags(ctx, dev, x)
         return acts
 
 
@@ -590,7 +660,7 @@ class ExplaiNN(_Model):
                 ctx.handle, self._x_ptr(ctx, x, dev), B, C.byref(ps),
                 select.data_ptr() if select is not None else None, unit_max.data_ptr(),
                 self._stream(dev)))
-            self._check_flags(ctx, dev)
+            self._check_flags(ctx, dev, x)
         return unit_max
 
     def filter_sites(self, x, thresholds, site_total, pfm, select=None, site_cap=1000000,
@@ -615,7 +685,7 @@ class ExplaiNN(_Model):
                 select.data_ptr() if select is not None else None, thresholds.data_ptr(),
                 int(site_cap), site_total.data_ptr(), pfm.data_ptr(),
                 hit.data_ptr() if hit is not None else None, self._stream(dev)))
-            self._check_flags(ctx, dev)
+            self._check_flags(ctx, dev, x)
         return hit
 
 

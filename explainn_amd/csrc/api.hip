@@ -56,7 +56,7 @@ void carve(explainn_ctx* c, Carver& cv) {
     cv.take(&c->qbar, U * NS);
     cv.take(&c->VC, U * FC_H * NS);
     cv.take(&c->A2, U * FC_H * NS);
-    cv.take(&c->A2f, U * FC_MT * fc_nk4q(c->NQ) * 256);
+    cv.take(&c->A2f, c->NQ <= FC_BF_MAXN ? 0 : U * FC_MT * fc_nk4q(c->NQ) * 256);
     cv.take(&c->A2h, c->NQ <= FC_BF_MAXN ? U * FC_MT * fc_ks32(c->NQ) * 3 * 256 : 0);
     cv.take(&c->sh2, U * FC_H);
     cv.take(&c->sig2, U * FC_H);
@@ -78,10 +78,7 @@ void carve(explainn_ctx* c, Carver& cv) {
     cv.take(&c->S12p, U * fc_ng(c->NQ) * (Bs / 16) * 2);
     cv.take(&c->Dspp, U * (Bs / 64) * K4);
     cv.take(&c->dlogits, (int64_t)c->maxB * c->T);
-    cv.take(&c->evpart, (int64_t)64 * Bs * 8);
-    cv.take(&c->evcount, Bs / 64 + 64);
     cv.take(&c->flags, 64);
-    cv.take(&c->seed_dev, 64);
     cv.take(&c->dlT, (int64_t)c->T * Bs);
     cv.take(&c->lossp, 64);
     cv.take(&c->site_cnt, U4 * Bs);
@@ -219,12 +216,10 @@ extern "C" int explainn_create(explainn_ctx** out, int cnn_units, int kernel_siz
     // from here on every failure releases what was acquired (explainn_destroy copes with the
     // members that are still null)
     int rc = [&]() -> int {
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->seed_ring), SEED_RING * 2 * sizeof(uint32_t), hipHostMallocDefault));
         TRY(prep_configure(c));
         TRY(bwd_configure(c));
         TRY(fc_configure(c));
         TRY(conv_configure(c));
-        TRY(eval_fused_configure(c));
         return EXPLAINN_OK;
     }();
     if (rc != EXPLAINN_OK) { explainn_destroy(c); return rc; }
@@ -238,8 +233,6 @@ extern "C" void explainn_destroy(explainn_ctx* c) {
         if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]);
         if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
     }
-    if (c->graph_exec) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(c->graph_exec));
-    if (c->seed_ring) (void)hipHostFree(c->seed_ring);
     if (c->base) (void)hipFree(c->base);
     delete c;
 }
@@ -257,12 +250,6 @@ extern "C" int explainn_forward_eval(explainn_ctx* c, const float* x, int B,
         TRY(launch_head_fwd(c, p, B, false, logits, nullptr, s));
         return EXPLAINN_OK;
     }
-    if (eval_fused_available(c)) {
-        // pack + ONE launch (few tasks), or + the combiner GEMM (many tasks)
-        TRY(launch_eval_fused(c, p, B, logits, false, s));
-        if (c->T > 8) TRY(launch_head_fwd(c, p, B, false, logits, nullptr, s));
-        return EXPLAINN_OK;
-    }
     TRY(launch_conv_pool(c, p, B, false, s));
     TRY(launch_fc_fwd(c, p, B, false, nullptr, 0.f, 0, s));
     TRY(launch_head_fwd(c, p, B, false, logits, nullptr, s));
@@ -277,8 +264,6 @@ extern "C" int explainn_unit_outputs(explainn_ctx* c, const float* x, int B,
     if (c->dense) {
         TRY(launch_dense_conv_pool(c, x, p, B, s));
         TRY(launch_fc_fwd(c, p, B, false, nullptr, 0.f, 0, s));
-    } else if (eval_fused_available(c)) {
-        TRY(launch_eval_fused(c, p, B, nullptr, true, s));
     } else {
         TRY(launch_conv_pool(c, p, B, false, s));
         TRY(launch_fc_fwd(c, p, B, false, nullptr, 0.f, 0, s));
@@ -481,105 +466,12 @@ int train_step_front(explainn_ctx* c, const float* x, const float* targets, int 
 }
 }  // namespace
 
-namespace {
-// ---- hipGraph replay of the whole step ------------------------------------------------------------
-// The step is 15 launches on two streams, identical from call to call when the caller reuses its
-// buffers (bench.py, a training loop over device-resident data).  Once the same arguments have
-// been seen three times in a row the step is captured (stream capture, the forked side stream
-// included) and from then on replayed with ONE hipGraphLaunch; only the dropout seed changes and
-// travels through device memory.  Any other argument change falls back to direct launches and
-// re-arms the capture.
-// OFF by default (EXPLAINN_GRAPH=1 turns it on): measured on MI355X / ROCm 7.2 the replay is not
-// faster than the direct launches -- 0.353 vs 0.343 ms at C2, 0.166 vs 0.164 ms at the C1 shape
-// (tools/graph_probe.py); the runtime already issues the launches back to back and the graph adds
-// its own dependencies.  Kept, tested, for runtimes where that changes.
-struct step_key {
-    const void* x; const void* y; const void* logits; const void* loss;
-    explainn_params p; explainn_grads g;
-    int B, loss_kind, freeze; float dropout_p;
-};
-
-bool graphs_enabled() {
-    const char* e = getenv("EXPLAINN_GRAPH");          // read per call: tests toggle it
-    return e && e[0] == '1';
-}
-
-int step_direct(explainn_ctx* c, const float* x, const float* targets, int B, const explainn_params* p,
-                const explainn_grads* g, int loss_kind, float dropout_p, uint64_t seed, int freeze,
-                float* logits, float* loss_out, void* stream) {
-    TRY(train_step_front(c, x, targets, B, p, g, loss_kind, dropout_p, seed, logits, loss_out, stream));
-    return backward_conv(c, B, p, g, freeze, static_cast<hipStream_t>(stream));
-}
-
-int push_seed(explainn_ctx* c, uint64_t seed, hipStream_t s) {
-    uint32_t* slot = c->seed_ring + 2 * (c->seed_slot++ % SEED_RING);
-    slot[0] = (uint32_t)seed; slot[1] = (uint32_t)(seed >> 32);
-    HIP_TRY(hipMemcpyAsync(c->seed_dev, slot, 2 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    return EXPLAINN_OK;
-}
-}  // namespace
-
 extern "C" int explainn_train_step(explainn_ctx* c, const float* x, const float* targets, int B,
                                    const explainn_params* p, const explainn_grads* g, int loss_kind,
                                    float dropout_p, uint64_t seed, int freeze_top_n_filters,
                                    float* logits, float* loss_out, void* stream) {
-    static_assert(sizeof(step_key) <= sizeof(c->graph_key), "graph key buffer too small");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    // stream 0 (the legacy default stream) cannot be captured; staged base codes change per call
-    const bool eligible = graphs_enabled() && c && x && p && g && s != nullptr && B > 1 && !c->dense;
-    if (!eligible)
-        return step_direct(c, x, targets, B, p, g, loss_kind, dropout_p, seed, freeze_top_n_filters,
-                           logits, loss_out, stream);
-    step_key key;
-    memset(&key, 0, sizeof(key));
-    key.x = x; key.y = targets; key.logits = logits; key.loss = loss_out; key.p = *p; key.g = *g;
-    key.B = B; key.loss_kind = loss_kind; key.freeze = freeze_top_n_filters; key.dropout_p = dropout_p;
-    if (c->graph_exec && memcmp(&key, c->graph_key, sizeof(key)) == 0) {
-        TRY(push_seed(c, seed, s));
-        HIP_TRY(hipGraphLaunch(static_cast<hipGraphExec_t>(c->graph_exec), s));
-        c->fwd_B = B; c->tail_B = 0; c->staged_B = 0;
-        return EXPLAINN_OK;
-    }
-    if (memcmp(&key, c->seen_key, sizeof(key)) == 0) ++c->seen_count;
-    else { memcpy(c->seen_key, &key, sizeof(key)); c->seen_count = 1; }
-    if (c->seen_count < 3)
-        return step_direct(c, x, targets, B, p, g, loss_kind, dropout_p, seed, freeze_top_n_filters,
-                           logits, loss_out, stream);
-    // capture (nothing executes), instantiate, then run this call through the graph as well
-    if (c->graph_exec) {
-        (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(c->graph_exec));
-        c->graph_exec = nullptr;
-    }
-    c->seen_count = 0;
-    hipGraph_t graph = nullptr;
-    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
-        (void)hipGetLastError();
-        return step_direct(c, x, targets, B, p, g, loss_kind, dropout_p, seed, freeze_top_n_filters,
-                           logits, loss_out, stream);
-    }
-    c->capturing = true;
-    const int rc = step_direct(c, x, targets, B, p, g, loss_kind, dropout_p, seed,
-                               freeze_top_n_filters, logits, loss_out, stream);
-    c->capturing = false;
-    const hipError_t ee = hipStreamEndCapture(s, &graph);
-    hipGraphExec_t exec = nullptr;
-    if (rc != EXPLAINN_OK || ee != hipSuccess || graph == nullptr ||
-        hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
-        (void)hipGetLastError();
-        if (graph) (void)hipGraphDestroy(graph);
-        // capture is not available here: run directly (and stop trying for this context)
-        c->seen_count = -(1 << 30);
-        return step_direct(c, x, targets, B, p, g, loss_kind, dropout_p, seed, freeze_top_n_filters,
-                           logits, loss_out, stream);
-    }
-    (void)hipGraphDestroy(graph);
-    c->graph_exec = exec;
-    memcpy(c->graph_key, &key, sizeof(key));
-    c->graph_key_len = (int)sizeof(key);
-    TRY(push_seed(c, seed, s));
-    HIP_TRY(hipGraphLaunch(exec, s));
-    c->fwd_B = B; c->tail_B = 0; c->staged_B = 0;
-    return EXPLAINN_OK;
+    TRY(train_step_front(c, x, targets, B, p, g, loss_kind, dropout_p, seed, logits, loss_out, stream));
+    return backward_conv(c, B, p, g, freeze_top_n_filters, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int explainn_train_step_fc(explainn_ctx* c, const float* x, const float* targets, int B,
@@ -649,6 +541,20 @@ extern "C" int explainn_stage_times(explainn_ctx* c, float* us, int cap) {
         }
     }
     c->timed = 0;
+    return EXPLAINN_OK;
+}
+
+extern "C" int explainn_debug_keep_bits(explainn_ctx* c, int B, uint32_t* out, void* stream) {
+    TRY(check_batch(c, B));
+    if (!out) { explainn_set_error("out is null"); return EXPLAINN_E_ARG; }
+    if (c->fwd_B != B) {
+        explainn_set_error("keep_bits(B=%d) without a train-mode forward of that batch in flight (last B=%d)",
+                           B, c->fwd_B);
+        return EXPLAINN_E_STATE;
+    }
+    HIP_TRY(hipMemcpy2DAsync(out, (size_t)B * sizeof(uint4), c->bits, (size_t)c->Bs * sizeof(uint4),
+                             (size_t)B * sizeof(uint4), (size_t)c->U, hipMemcpyDeviceToDevice,
+                             static_cast<hipStream_t>(stream)));
     return EXPLAINN_OK;
 }
 

@@ -8,7 +8,6 @@
 #include "../../include/explainn_hip.h"
 
 #define FC_H 100          // hidden width of the per-unit FC (architectures/__init__.py:86)
-#define SEED_RING 1024      // pinned host slots the per-step dropout seeds are copied from (graph replay)
 #define HEAD_RB 8            // head kernels keep up to HEAD_RB*256 sequences per unit in registers
 #define HEAD_GEMM_MIN_T 8   // more tasks than this: combiner forward/backward as MFMA GEMMs (head.hip)
 #define POOLW 7           // MaxPool1d(7,7)        (architectures/__init__.py:81)
@@ -88,16 +87,6 @@ struct explainn_ctx {
     float* dlogits;       // [maxB][T]         (train_step only)
     float* dlT;           // [T][Bs]   d loss / d logits, task-major (head GEMMs, T > HEAD_GEMM_MIN_T)
     double* lossp;        // [64]      per-block partial sums of the loss
-    // hipGraph replay of explainn_train_step (api.hip): the step is captured once its arguments
-    // have repeated, then replayed with one launch; the dropout seed travels through seed_dev
-    uint32_t* seed_dev;   // [2]   device copy of the current seed (read by fc_fwd when captured)
-    uint32_t* seed_ring;  // [SEED_RING][2] pinned host ring the seeds are copied from
-    unsigned seed_slot;
-    bool capturing;
-    void* graph_exec;     // hipGraphExec_t
-    unsigned char graph_key[512];
-    unsigned char seen_key[512];
-    int graph_key_len, seen_count;
     int staged_B;         // batch size of the codes explainn_stage_codes() staged, 0 = none
     // eval-mode tables (filter tables, BatchNorm1/2 folds, FC1 fragments) held in the scratch are
     // those of parameter version eval_version; a train-mode forward overwrites them
@@ -106,8 +95,6 @@ struct explainn_ctx {
     // soft (not one-hot) input: explainn_dense_input switches the stages that touch x to dense.hip
     bool dense;
     const float* dense_x;  // x of the train forward in flight (its backward reads it again)
-    float* evpart;        // [64][Bs][8] per-unit-group partial logits of the fused eval kernel
-    int* evcount;         // [Bs/64]     arrival counters of its sequence tiles (zero between launches)
     int* flags;           // [1]
     int* site_cnt;        // [U4][Bs]  sites per (unit, sequence) of the current batch (filter->PWM export)
     int* site_off;        // [U4][Bs]  their exclusive scan in sequence order, plus the running total
@@ -183,10 +170,6 @@ int prep_configure(explainn_ctx* c);
 int bwd_configure(explainn_ctx* c);
 int fc_configure(explainn_ctx* c);
 int conv_configure(explainn_ctx* c);
-int eval_fused_configure(explainn_ctx* c);
-bool eval_fused_available(const explainn_ctx* c);
-int launch_eval_fused(explainn_ctx* c, const explainn_params* p, int B, float* logits, bool write_o,
-                      hipStream_t s);
 
 // In-kernel stamps (tools/stampbench.hip defines EXPLAINN_STAMP; the library build compiles them out)
 #ifdef EXPLAINN_STAMP

@@ -352,276 +352,3 @@ int launch_conv_act(explainn_ctx* c, int B, float* acts, hipStream_t s) {
     LAUNCH_CHECK();
     return EXPLAINN_OK;
 }
-
-// ---------------------------------------------------------------------------------------------
-// Eval-mode forward in ONE launch behind the pack kernel (architectures/__init__.py:109-114 with
-// every BatchNorm folded; callers predict.py:81-82, selene/__init__.py:334): filter bank -> pooling
-// -> exp -> FC1 (+BN2, ReLU) -> FC2 (+BN3, ReLU) -> final combiner.  Nothing of size (B,U,n) goes
-// through HBM: the pooled activations live in LDS between the gather and the matrix cores.
-//
-// Workgroup = 4 wavefronts = one tile of 64 sequences x a group of units, walked two units at a time:
-//   phase A  the four waves split the pooling windows of the pair (lane = sequence; the code tiles
-//            are staged once per workgroup, they do not depend on the unit) and write
-//            q = exp(alpha*ext + shift) to LDS;
-//   phase B  wave w takes sequences [16w, 16w+16) of the tile: FC1 on the exact-fp32 MFMA
-//            (16x16x4, the eval-folded weight fragments prep2 left in A2f staged in LDS), ReLU, FC2,
-//            BatchNorm3 + ReLU, and -- for T <= EVAL_MAX_T tasks -- the unit's contribution to
-//            the logits of its 16 sequences, kept in registers.
-// The per-group partial logits are combined by the LAST workgroup of each sequence tile to arrive
-// (agent-scope release / acquire around a per-tile counter), in fixed group order: deterministic.
-// Many tasks (T > EVAL_MAX_T) or the unit-output export: o[u][b] is written instead and the
-// combiner GEMM of head.hip follows.
-// ---------------------------------------------------------------------------------------------
-typedef float f32x4e __attribute__((ext_vector_type(4)));
-#define EVAL_MAX_T 8
-#define EVAL_QLD 80       // row stride of the q tile: rows g and g+1 of an operand read land 16 banks apart
-
-template <int K>
-__global__ __launch_bounds__(256) void eval_fused_kernel(
-    const uint32_t* __restrict__ pk2, const uint32_t* __restrict__ nmask,
-    const float2* __restrict__ lut, const float* __restrict__ Wt, const float* __restrict__ gamma1,
-    const float* __restrict__ alpha, const float* __restrict__ shift, const float* __restrict__ A2f,
-    const float* __restrict__ sh2, const float* __restrict__ V2, const float* __restrict__ c2,
-    const float* __restrict__ g3, const float* __restrict__ b3, const float* __restrict__ rm3,
-    const float* __restrict__ rv3, const float* __restrict__ Wf, const float* __restrict__ bf,
-    float* __restrict__ oout, float* __restrict__ partial, int* __restrict__ counters,
-    float* __restrict__ logits, int U, int n, int T, int Bs, int B, int PW, int NW, int upg,
-    int nk4, int nk4q, int write_o, int pneed, int nneed) {
-    constexpr int NT = (K + 1) / 2;
-    constexpr int CPW = 32;
-    constexpr int PWC = ((POOLW * CPW + K + 15) >> 4) + 3, NWC = ((POOLW * CPW + K + 31) >> 5) + 2;
-    extern __shared__ __attribute__((aligned(256))) uint32_t esm[];
-    float2* L2 = reinterpret_cast<float2*>(esm);                       // [NT][16]
-    float2* Wp = L2 + NT * 16;                                         // [K][5]
-    // code tiles, one per wave, sized for the windows a wave really has (n <= 40: at most 10):
-    // pneed packed-code rows and nneed N-mask rows of 64 words
-    uint32_t* codes = reinterpret_cast<uint32_t*>(Wp + ((K * 5 + 1) & ~1));   // 4 x ([pneed] + [nneed])[64]
-    float* qs = reinterpret_cast<float*>(codes + 4 * (pneed + nneed) * 64); // [2][4*nk4][EVAL_QLD]
-    const int qrows = 4 * nk4;
-    float* Af = qs + 2 * qrows * EVAL_QLD;                             // [2][FC_MT][nk4q][64][4]
-    float* sv = Af + 2 * FC_MT * nk4q * 256;                           // [2][2][112]: sh2, v2
-    __shared__ int last_flag;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile = blockIdx.x, grp = blockIdx.y;
-    const int b = tile * 64 + lane;                                    // phase A: lane = sequence
-    const int c = lane & 15, g = lane >> 4;                            // phase B: MFMA fragment coordinates
-    const int ub = grp * upg, ue = min(U, ub + upg);
-    // windows of this wave
-    const int wper = (n + 3) / 4;
-    const int wbeg = min(n, wave * wper), wend = min(n, wbeg + wper);
-    uint32_t* pks = codes + wave * (pneed + nneed) * 64;
-    uint32_t* nms = pks + pneed * 64;
-    const bool one_chunk = true;                       // the launcher admits n <= 40 only
-    if (wbeg < wend) {
-        const int w_lo = (POOLW * wbeg) >> 4, n_lo = (POOLW * wbeg) >> 5;
-        stage_columns2<PWC, NWC>(pks + lane, pk2 + (size_t)w_lo * Bs + b, min(pneed, PW - w_lo),
-                                 nms + lane, nmask + (size_t)n_lo * Bs + b, min(nneed, NW - n_lo), Bs);
-    }
-    float lacc[EVAL_MAX_T];
-#pragma unroll
-    for (int t = 0; t < EVAL_MAX_T; ++t) lacc[t] = 0.f;
-    for (int u0 = ub; u0 < ue; u0 += 2) {
-        const int pair = u0 >> 1;                      // ub is even (upg is even)
-        __syncthreads();                               // previous pair's phase B is done with LDS
-        // ---- stage the pair's tables: LUT, per-tap table, FC1 fragments, sh2 / v2 ----
-        {
-            const float4* src = reinterpret_cast<const float4*>(lut) + (size_t)(pair >> 1) * NT * 16;
-            for (int i = tid; i < NT * 16; i += 256) {
-                const float4 v = src[i];
-                L2[i] = (pair & 1) ? make_float2(v.z, v.w) : make_float2(v.x, v.y);
-            }
-            const int quad = pair >> 1, off = (pair & 1) * 2;
-            for (int i = tid; i < K * 5; i += 256) {
-                const float* wq = Wt + ((size_t)quad * K + i / 5) * 20 + (i % 5) * 4 + off;
-                Wp[i] = make_float2(wq[0], wq[1]);
-            }
-            const int n4 = FC_MT * nk4q * 64;          // float4 per unit
-            for (int uu = 0; uu < 2; ++uu) {
-                const int u = min(u0 + uu, U - 1);
-                const float4* a4 = reinterpret_cast<const float4*>(A2f) + (size_t)u * n4;
-                float4* d4 = reinterpret_cast<float4*>(Af) + (size_t)uu * n4;
-                for (int i = tid; i < n4; i += 256) d4[i] = a4[i];
-                if (tid < FC_MT * 16) {
-                    sv[(uu * 2 + 0) * 112 + tid] = tid < FC_H ? sh2[(size_t)u * FC_H + tid] : 0.f;
-                    sv[(uu * 2 + 1) * 112 + tid] = tid < FC_H ? V2[(size_t)u * FC_H + tid] : 0.f;
-                }
-            }
-        }
-        const float sg[2] = {(gamma1[u0] < 0.f) ? -1.f : 1.f,
-                             (u0 + 1 < U && gamma1[u0 + 1] < 0.f) ? -1.f : 1.f};
-        const float al0 = alpha[u0], sf0 = shift[u0];
-        const float al1 = alpha[min(u0 + 1, U - 1)], sf1 = shift[min(u0 + 1, U - 1)];
-        __syncthreads();
-        // ---- phase A: gather + pool + exp -> q tile ----
-        conv_pool_windows<K, 2, CPW>(L2, Wp, pks, nms, pk2, nmask, sg, b, lane, wbeg, wend, Bs, PW, NW,
-                                [&](int w, const float (&e)[2], const int (&)[2]) {
-                                    qs[w * EVAL_QLD + lane] = qval(al0, e[0], sf0);
-                                    qs[(qrows + w) * EVAL_QLD + lane] = qval(al1, e[1], sf1);
-                                }, one_chunk);
-        // rows n .. 4*nk4-1 are the zero padding of the last k-step
-        for (int i = tid; i < 2 * (qrows - n) * 64; i += 256) {
-            const int uu = i / ((qrows - n) * 64), r = (i / 64) % (qrows - n), l = i & 63;
-            qs[(uu * qrows + n + r) * EVAL_QLD + l] = 0.f;
-        }
-        __syncthreads();
-        // ---- phase B: FC1 (MFMA) -> ReLU -> FC2 -> BN3 -> ReLU -> logits ----
-#pragma unroll 1
-        for (int uu = 0; uu < 2; ++uu) {
-            const int u = u0 + uu;
-            if (u >= ue) break;
-            const float* q_u = qs + uu * qrows * EVAL_QLD + 16 * wave + c;
-            const float4* Afu = reinterpret_cast<const float4*>(Af) + (size_t)uu * FC_MT * nk4q * 64;
-            const float* sh2s = sv + (uu * 2) * 112;
-            const float* v2s = sh2s + 112;
-            f32x4e acc[FC_MT];
-#pragma unroll
-            for (int t = 0; t < FC_MT; ++t) {
-                const float4 v = *reinterpret_cast<const float4*>(&sh2s[16 * t + 4 * g]);
-                acc[t][0] = v.x; acc[t][1] = v.y; acc[t][2] = v.z; acc[t][3] = v.w;
-            }
-#pragma unroll 1
-            for (int sq = 0; sq < nk4q; ++sq) {
-                float qv[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) qv[e] = (4 * sq + e < nk4) ? q_u[(4 * (4 * sq + e) + g) * EVAL_QLD] : 0.f;
-#pragma unroll
-                for (int t = 0; t < FC_MT; ++t) {
-                    const float4 a = Afu[(t * nk4q + sq) * 64 + lane];
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, qv[0], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, qv[1], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, qv[2], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, qv[3], acc[t], 0, 0, 0);
-                }
-            }
-            float zp = 0.f;
-#pragma unroll
-            for (int t = 0; t < FC_MT; ++t) {
-                const float4 v2 = *reinterpret_cast<const float4*>(&v2s[16 * t + 4 * g]);
-                zp = fmaf(v2.x, fmaxf(acc[t][0], 0.f), zp);
-                zp = fmaf(v2.y, fmaxf(acc[t][1], 0.f), zp);
-                zp = fmaf(v2.z, fmaxf(acc[t][2], 0.f), zp);
-                zp = fmaf(v2.w, fmaxf(acc[t][3], 0.f), zp);
-            }
-            zp += __shfl_xor(zp, 16, 64);
-            zp += __shfl_xor(zp, 32, 64);
-            const float inv = g3[u] / sqrtf(rv3[u] + (float)BN_EPS_D);
-            const float ov = fmaxf(fmaf(inv, zp + c2[u] - rm3[u], b3[u]), 0.f);
-            if (write_o) {
-                if (g == 0) oout[(size_t)u * Bs + tile * 64 + 16 * wave + c] = ov;
-            } else {
-#pragma unroll
-                for (int t = 0; t < EVAL_MAX_T; ++t)
-                    if (t < T) lacc[t] = fmaf(Wf[(size_t)t * U + u], ov, lacc[t]);
-            }
-        }
-    }
-    if (write_o) return;
-    // ---- partial logits of this unit group -> the last group of the tile adds them up ----
-    const int NG = gridDim.y;
-    if (g == 0) {
-        const int bb = tile * 64 + 16 * wave + c;
-#pragma unroll
-        for (int t = 0; t < EVAL_MAX_T; ++t)
-            if (t < T) partial[((size_t)grp * Bs + bb) * EVAL_MAX_T + t] = lacc[t];
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int ticket = atomicAdd(&counters[tile], 1);
-        const int last = ticket == NG - 1;
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            counters[tile] = 0;                        // ready for the next launch
-        }
-        last_flag = last;
-    }
-    __syncthreads();
-    if (!last_flag) return;
-    for (int e = tid; e < 64 * T; e += 256) {
-        const int bl = e / T, t = e % T, bb = tile * 64 + bl;
-        if (bb >= B) continue;
-        float sum = bf[t];
-        for (int gq = 0; gq < NG; ++gq)                // fixed order: bitwise reproducible
-            sum += partial[((size_t)gq * Bs + bb) * EVAL_MAX_T + t];
-        logits[(size_t)bb * T + t] = sum;
-    }
-}
-
-static void eval_code_rows(const explainn_ctx* c, int* pneed, int* nneed) {
-    const int wper = (c->n + 3) / 4;                   // windows per wave
-    *pneed = ((POOLW * wper + c->k + 15) >> 4) + 3;
-    *nneed = ((POOLW * wper + c->k + 31) >> 5) + 2;
-}
-
-static size_t eval_fused_lds(const explainn_ctx* c) {
-    const int K = c->k, NT = (K + 1) / 2;
-    int pwc, nwc;
-    eval_code_rows(c, &pwc, &nwc);
-    const int nk4 = fc_nk4(c->NQ), nk4q = fc_nk4q(c->NQ);
-    return (size_t)(NT * 16 + ((K * 5 + 1) & ~1)) * sizeof(float2) + (size_t)4 * (pwc + nwc) * 64 * 4 +
-           (size_t)2 * 4 * nk4 * EVAL_QLD * 4 + (size_t)2 * FC_MT * nk4q * 256 * 4 + (size_t)4 * 112 * 4;
-}
-
-bool eval_fused_available(const explainn_ctx* c) {
-    // OPT-IN (EXPLAINN_EVAL_FUSED=1, read per call: tests toggle it).  Measured on MI355X at the C2
-    // shape this single launch is SLOWER than filter bank + FC + combiner as three launches over
-    // the cached tables: 0.147 vs 0.10 ms at B = 1024, 0.45 vs 0.23 ms at B = 4096.  Its 64 KB of
-    // LDS per workgroup leave two workgroups (2 waves per SIMD) per CU, and both of its phases --
-    // an issue-bound gather and a latency-bound MFMA chain -- live on having 4-5 waves per SIMD.
-    // Kept, tested, as the starting point for a smaller-footprint version.
-    const char* e = getenv("EXPLAINN_EVAL_FUSED");
-    if (!(e && e[0] == '1')) return false;
-    // q tiles and two units' weight fragments must fit the LDS next to the code tiles
-    return c->n <= 40 && eval_fused_lds(c) <= 80 * 1024;
-}
-
-// unit groups per sequence tile: enough workgroups to fill the chip (two fit a CU), an even number
-// of units each
-static int eval_groups(const explainn_ctx* c, int B, int* upg_out) {
-    const int tiles = (B + 63) / 64;
-    int groups = (640 + tiles - 1) / tiles;
-    const int pairs = (c->U + 1) / 2;
-    if (groups > pairs) groups = pairs;
-    if (groups > 64) groups = 64;                       // scratch for the partial logits
-    if (groups < 1) groups = 1;
-    int upg = 2 * ((pairs + groups - 1) / groups);
-    groups = (c->U + upg - 1) / upg;
-    *upg_out = upg;
-    return groups;
-}
-
-int launch_eval_fused(explainn_ctx* c, const explainn_params* p, int B, float* logits, bool write_o,
-                      hipStream_t s) {
-    int upg = 2;
-    const int groups = eval_groups(c, B, &upg);
-    const dim3 grid((B + 63) / 64, groups);
-    const size_t sm = eval_fused_lds(c);
-    const int wo = (write_o || c->T > EVAL_MAX_T) ? 1 : 0;
-    int pneed, nneed;
-    eval_code_rows(c, &pneed, &nneed);
-#define CALL(KK)                                                                                   \
-    hipLaunchKernelGGL(eval_fused_kernel<KK>, grid, dim3(256), sm, s, c->pk2, c->nmask,            \
-                       reinterpret_cast<const float2*>(c->lut), c->Wt, p->bn1_w, c->alpha, c->shift, \
-                       c->A2f, c->sh2, p->fc2_w, p->fc2_b, p->bn3_w, p->bn3_b, p->bn3_rm, p->bn3_rv, \
-                       p->final_w, p->final_b, c->o, c->evpart, c->evcount, logits, c->U, c->n, c->T, \
-                       c->Bs, B, c->PW, c->NW, upg, fc_nk4(c->NQ), fc_nk4q(c->NQ), wo, pneed, nneed)
-    K_DISPATCH(c->k, CALL);
-#undef CALL
-    LAUNCH_CHECK();
-    return EXPLAINN_OK;
-}
-
-int eval_fused_configure(explainn_ctx* c) {
-    const size_t sm = eval_fused_lds(c);
-    if (c->n <= 40 && sm <= 80 * 1024 && sm > 48 * 1024) {
-#define CALL(KK)                                                                            \
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_fused_kernel<KK>),  \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm))
-        K_DISPATCH(c->k, CALL);
-#undef CALL
-    }
-    return EXPLAINN_OK;
-}

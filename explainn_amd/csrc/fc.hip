@@ -105,13 +105,10 @@ __global__ __launch_bounds__(64 * fc_fwd_waves(NQ)) void fc_fwd_kernel(
     const uint8_t* __restrict__ keep_mask, uint32_t thresh16, float scale, uint32_t seed_lo,
     uint32_t seed_hi, const float* __restrict__ c2, const float* __restrict__ g3,
     const float* __restrict__ b3, const float* __restrict__ rm3, const float* __restrict__ rv3,
-    float* __restrict__ oout, int n, int Bs, int B, int U, const uint32_t* __restrict__ seed_dev,
+    float* __restrict__ oout, int n, int Bs, int B, int U,
     double* __restrict__ z12p) {
     constexpr int NK4 = fc_nk4(NQ), NK4Q = fc_nk4q(NQ), FW = fc_fwd_waves(NQ), NTH = 64 * FW;
     constexpr bool TRAIN = MODE != 0;
-    // a captured step (hipGraph) reads its dropout seed from device memory, so that replays can
-    // use a new one; direct launches pass it by value
-    if (MODE == 2 && seed_dev) { seed_lo = seed_dev[0]; seed_hi = seed_dev[1]; }
     extern __shared__ __attribute__((aligned(16))) float fsm[];
     float4* Af = reinterpret_cast<float4*>(fsm);            // [FC_MT][NK4Q][64] float4 (4 k-steps each)
     float* sh2s = fsm + FC_MT * NK4Q * 64 * 4;               // [112]
@@ -247,11 +244,10 @@ __global__ __launch_bounds__(64 * fc_fwd_waves(NQ), fc_ks32(NQ) == 1 ? 5 : 2) vo
     const uint8_t* __restrict__ keep_mask, uint32_t thresh16, float scale, uint32_t seed_lo,
     uint32_t seed_hi, const float* __restrict__ c2, const float* __restrict__ g3,
     const float* __restrict__ b3, const float* __restrict__ rm3, const float* __restrict__ rv3,
-    float* __restrict__ oout, int n, int Bs, int B, int U, const uint32_t* __restrict__ seed_dev,
+    float* __restrict__ oout, int n, int Bs, int B, int U,
     double* __restrict__ z12p) {
     constexpr int KS = fc_ks32(NQ), FW = fc_fwd_waves(NQ), NTH = 64 * FW;
     constexpr bool TRAIN = MODE != 0;
-    if (MODE == 2 && seed_dev) { seed_lo = seed_dev[0]; seed_hi = seed_dev[1]; }
     extern __shared__ __attribute__((aligned(16))) float fsm[];
     u32x4* Ah = reinterpret_cast<u32x4*>(fsm);               // [FC_MT][KS][3][64] x 8 bf16
     float* sh2s = fsm + FC_MT * KS * 3 * 256;                // [112]
@@ -406,18 +402,17 @@ template <int N, int MODE>
 static void fc_fwd_launch_nm(explainn_ctx* c, const explainn_params* p, int B, dim3 grid,
                              const uint8_t* keep_mask, uint32_t thresh, float scale, uint64_t seed,
                              hipStream_t s) {
-    const uint32_t* sd = c->capturing ? c->seed_dev : (const uint32_t*)nullptr;
     if constexpr (N <= FC_BF_MAXN)
         hipLaunchKernelGGL((fc_fwd_bf_kernel<N, MODE>), grid, dim3(64 * fc_fwd_waves(N)), fc_fwd_bf_lds<N>(), s, c->ext,
                            c->alpha, c->shift, reinterpret_cast<const uint32_t*>(c->A2h), c->sh2,
                            p->fc2_w, c->bits, c->z, keep_mask, thresh, scale, (uint32_t)seed,
                            (uint32_t)(seed >> 32), p->fc2_b, p->bn3_w, p->bn3_b, p->bn3_rm, p->bn3_rv,
-                           c->o, c->n, c->Bs, B, c->U, sd, c->z12p);
+                           c->o, c->n, c->Bs, B, c->U, c->z12p);
     else
         hipLaunchKernelGGL((fc_fwd_kernel<N, MODE>), grid, dim3(64 * fc_fwd_waves(N)), fc_fwd_lds<N>(), s, c->ext,
                            c->alpha, c->shift, c->A2f, c->sh2, p->fc2_w, c->bits, c->z, keep_mask,
                            thresh, scale, (uint32_t)seed, (uint32_t)(seed >> 32), p->fc2_b, p->bn3_w,
-                           p->bn3_b, p->bn3_rm, p->bn3_rv, c->o, c->n, c->Bs, B, c->U, sd, c->z12p);
+                           p->bn3_b, p->bn3_rm, p->bn3_rv, c->o, c->n, c->Bs, B, c->U, c->z12p);
 }
 
 template <int N, int MODE>
@@ -610,7 +605,11 @@ __host__ __device__ constexpr int pa_wgt(int NQ) { return pa_nw16(NQ) <= 2 ? pa_
 __host__ __device__ constexpr int pa_ng(int NQ) { return (pa_nw16(NQ) + pa_wgt(NQ) - 1) / pa_wgt(NQ); }
 
 #define PA_WAVES 2                    // wavefronts per passA workgroup: their tiles are added in LDS before the store
-template <int NQ>
+// HEAD: the instantiation that carries the head backward in its prologue (few tasks, batch <= 512).
+// The plain one -- what the headline shape launches -- does not hold pa_head_args' 18 pointers in
+// SGPRs across the main loop: with them passA<26> spilled 88 SGPRs and 12 VGPRs (20 B of scratch per
+// lane, tools/check_resources.py now fails the build on that).
+template <int NQ, bool HEAD>
 __global__ __launch_bounds__(64 * PA_WAVES, pa_wgt(NQ) <= 2 ? 3 : 2) void passA_kernel(const float* __restrict__ ext,
                                                    const float* __restrict__ alpha,
                                                    const float* __restrict__ shift,
@@ -622,13 +621,14 @@ __global__ __launch_bounds__(64 * PA_WAVES, pa_wgt(NQ) <= 2 ? 3 : 2) void passA_
     constexpr int NS = ns_stride(NQ), WGT = pa_wgt(NQ), ROWS = 16 * WGT;
     // per wave: the X image [piece][row][sequence] bf16 and the bit words [sequence][4]; the region of
     // wave 1 doubles as the buffer its accumulator tile crosses to wave 0 in at the end
-    constexpr int XT_HALFS = 3 * ROWS * PA_LD, REGION = XT_HALFS * 2 + 64 * 4 * 4;
+    // (the bit words are double-buffered: the next super-tile's arrive by LDS-DMA during the MFMAs)
+    constexpr int XT_HALFS = 3 * ROWS * PA_LD, REGION = XT_HALFS * 2 + 2 * 64 * 4 * 4;
     static_assert(REGION >= FC_MT * WGT * 64 * 16, "accumulator tile must fit the wave's LDS region");
     __shared__ __attribute__((aligned(16))) unsigned char pal[PA_WAVES][REGION];
     const int u = blockIdx.y, ch = blockIdx.x, grp = blockIdx.z, lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: LDS bases stay scalar
     uint16_t* xt = reinterpret_cast<uint16_t*>(pal[wave]);
-    uint32_t* tw = reinterpret_cast<uint32_t*>(pal[wave] + XT_HALFS * 2);
+    uint32_t* tw0 = reinterpret_cast<uint32_t*>(pal[wave] + XT_HALFS * 2);      // [2][64 sequences][4 words]
     const int c = lane & 15, g = lane >> 4;
     const int w0 = grp * ROWS;                         // first column of this group
     // a workgroup owns one of the ACH batch chunks; its PA_WAVES waves split it in 64-sequence tiles
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(64 * PA_WAVES, pa_wgt(NQ) <= 2 ? 3 : 2) void passA_
     const float* __restrict__ eu = ext + (size_t)u * n * Bs;
     const float* __restrict__ dzu = dz + (size_t)u * Bs;
     const uint4* __restrict__ bu = bits + (size_t)u * Bs;
-    if (h.mode) pa_head_prologue(h, u, ch + wave, grp, lane, bbeg, bend, Bs, B, U);   // (owner: chunk 0, wave 0)
+    if (HEAD) pa_head_prologue(h, u, ch + wave, grp, lane, bbeg, bend, Bs, B, U);     // (owner: chunk 0, wave 0)
     f32x4 acc[FC_MT][WGT];
 #pragma unroll
     for (int t = 0; t < FC_MT; ++t)
@@ -647,29 +647,45 @@ __global__ __launch_bounds__(64 * PA_WAVES, pa_wgt(NQ) <= 2 ? 3 : 2) void passA_
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[t][j][i] = 0.f;
     float rq[ROWS], rdz = 0.f;
-    uint4 rw = make_uint4(0u, 0u, 0u, 0u);
-    auto fetch = [&](int b0) {
+    // fetch = loads only.  Nothing here USES a loaded value: a use (even an empty asm pin) makes the
+    // compiler wait for the data on the spot, and the point of issuing the next super-tile's loads
+    // before the MFMAs is that they return while the matrix core works.  The values are turned
+    // into X at the top of the next iteration, behind one s_waitcnt.
+    auto fetch = [&](int b0, int slot) {
         const int b = b0 + lane;
-        const bool live = b < bend;
-        const int bc = live ? b : bbeg;
+        const int bc = b < bend ? b : bbeg;
+        // the 16 bytes of bit words per sequence go global -> LDS directly (global_load_lds_dwordx4:
+        // destination = wave-uniform base + 16 * lane, exactly the [sequence][4] image): held in
+        // registers across the MFMA phase they were the four registers the allocator spilled
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(bu + bc),
+            (__attribute__((address_space(3))) void*)(tw0 + slot * 256), 16, 0, 0);
+        // one scalar base + a 32-bit byte offset per row (global_load ... saddr): per-row 64-bit
+        // vector addresses cost 2 x ROWS registers
+        const char* __restrict__ eb = reinterpret_cast<const char*>(eu);
+        const uint32_t boff = (uint32_t)bc * 4u, rstride = (uint32_t)Bs * 4u;
 #pragma unroll
-        for (int i = 0; i < ROWS; ++i) rq[i] = eu[min(w0 + i, n - 1) * Bs + bc];
+        for (int i = 0; i < ROWS; ++i)
+            rq[i] = *reinterpret_cast<const float*>(eb + (boff + (uint32_t)min(w0 + i, n - 1) * rstride));
         rdz = dzu[bc];
-        rw = bu[bc];
-#pragma unroll
-        for (int i = 0; i < ROWS; ++i) KEEP(rq[i]);
-        KEEP(rdz);
-        rdz = live ? rdz : 0.f;
-        // X[b][w] = dz q (w < n), dz (w == n: the Se column), 0 beyond
-#pragma unroll
-        for (int i = 0; i < ROWS; ++i) {
-            const int w = w0 + i;
-            rq[i] = w < n ? rdz * qval(a1, rq[i], sh1) : (w == n ? rdz : 0.f);
-        }
     };
     STAMP(0);
-    if (bbeg < bend) fetch(bbeg);
-    for (int b0 = bbeg; b0 < bend; b0 += 64) {
+    if (bbeg < bend) fetch(bbeg, 0);
+    int slot = 0;
+    for (int b0 = bbeg; b0 < bend; b0 += 64, slot ^= 1) {
+        const uint32_t* tw = tw0 + slot * 256;
+        // everything of fetch(b0) has landed: the q rows are about to be used, and the LDS-DMA of the
+        // bit words is ordered before this wave's reads of them by this wait alone (wave-private image)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        {
+            // X[b][w] = dz q (w < n), dz (w == n: the Se column), 0 beyond; dead lanes carry zeros
+            const float dzv = (b0 + lane < bend) ? rdz : 0.f;
+#pragma unroll
+            for (int i = 0; i < ROWS; ++i) {
+                const int w = w0 + i;
+                rq[i] = w < n ? dzv * qval(a1, rq[i], sh1) : (w == n ? dzv : 0.f);
+            }
+        }
         // three bf16 pieces of every X value into the LDS image (the store takes the upper half of
         // the register)
 #pragma unroll
@@ -683,9 +699,9 @@ __global__ __launch_bounds__(64 * PA_WAVES, pa_wgt(NQ) <= 2 ? 3 : 2) void passA_
             xt[(1 * ROWS + i) * PA_LD + lane] = (uint16_t)(mb >> 16);
             xt[(2 * ROWS + i) * PA_LD + lane] = (uint16_t)(__float_as_uint(r2) >> 16);
         }
-        *reinterpret_cast<uint4*>(&tw[lane * 4]) = rw;
         if (b0 == bbeg) STAMP(1);
-        if (b0 + 64 < bend) fetch(b0 + 64);           // in flight during the MFMAs below
+        if (b0 + 64 < bend) fetch(b0 + 64, slot ^ 1); // in flight during the MFMAs below
+        __builtin_amdgcn_sched_barrier(0);            // (issued HERE, not wherever the scheduler likes)
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {               // 32 sequences per MFMA
@@ -773,9 +789,14 @@ int launch_passA(explainn_ctx* c, int B, const pa_head_args* head, hipStream_t s
     pa_head_args h = {};
     if (head) h = *head;
 #define CALL(N)                                                                                  \
-    hipLaunchKernelGGL(passA_kernel<N>, dim3(c->ACH, c->U, pa_ng(N)), dim3(64 * PA_WAVES), 0, s, \
-                       c->ext, c->alpha, c->shift, c->dz, c->bits, c->EQp, c->Sep, c->n, c->Bs,  \
-                       B, c->ACH, h, c->U)
+    if (h.mode)                                                                                  \
+        hipLaunchKernelGGL((passA_kernel<N, true>), dim3(c->ACH, c->U, pa_ng(N)), dim3(64 * PA_WAVES), 0, s, \
+                           c->ext, c->alpha, c->shift, c->dz, c->bits, c->EQp, c->Sep, c->n, c->Bs, \
+                           B, c->ACH, h, c->U);                                                  \
+    else                                                                                         \
+        hipLaunchKernelGGL((passA_kernel<N, false>), dim3(c->ACH, c->U, pa_ng(N)), dim3(64 * PA_WAVES), 0, s, \
+                           c->ext, c->alpha, c->shift, c->dz, c->bits, c->EQp, c->Sep, c->n, c->Bs, \
+                           B, c->ACH, h, c->U)
     NQ_DISPATCH(c->NQ, CALL);
 #undef CALL
     LAUNCH_CHECK();

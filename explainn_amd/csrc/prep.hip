@@ -383,7 +383,7 @@ static size_t qmom_big_lds() {
 
 int launch_qmoments(explainn_ctx* c, int B, hipStream_t s) {
 #define CALL(N)                                                                                  \
-    if ((N) <= 32)                                                                               \
+    if constexpr ((N) <= 32)      /* (constexpr: only the form a bucket uses is instantiated) */  \
         hipLaunchKernelGGL(qmom_kernel<N>, dim3(c->QCH, c->U, 1), dim3(64), 0, s, c->ext,        \
                            c->alpha, c->shift, c->qs0, c->qS1p, c->qS2p, c->n, c->Bs, B, c->QCH); \
     else                                                                                         \
@@ -665,10 +665,10 @@ __global__ __launch_bounds__(1024) void prep2_kernel(
 }
 
 int launch_prep2(explainn_ctx* c, const explainn_params* p, int B, bool train, hipStream_t s) {
-    // fragment images of the folded weights: the bf16 pieces for fc_fwd where it runs on the bf16
-    // matrix core, the fp32 fragments for the large-n fc_fwd and for the (opt-in) single-launch eval
+    // fragment image of the folded weights: the bf16 pieces where fc_fwd runs on the bf16 matrix
+    // core (n <= FC_BF_MAXN), the fp32 fragments for the large-n fc_fwd
     uint32_t* a2h = c->NQ <= FC_BF_MAXN ? reinterpret_cast<uint32_t*>(c->A2h) : nullptr;
-    float* a2f = (!a2h || !train) ? c->A2f : nullptr;   // (eval tables are cached: always complete)
+    float* a2f = a2h ? nullptr : c->A2f;
     if (train)
         hipLaunchKernelGGL(prep2_kernel<true>, dim3(c->U), dim3(1024), prep2_lds(c->n, c->NS), s,
                            p->fc1_w, p->fc1_b, p->bn2_w, p->bn2_b, p->bn2_rm, p->bn2_rv, p->bn2_nbt,

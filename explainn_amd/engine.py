@@ -73,7 +73,11 @@ class StepEngine:
         if not (torch.is_tensor(x) and x.dtype == torch.float32):
             x = m._prep_input(x, self.dev)
         stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
-        xp = m._x_ptr(self.ctx, x, self.dev, validate=False)   # the Trainer reads the sticky flag periodically
+        # the model's own validation schedule (architectures.ExplaiNN.validate_input): the first
+        # steps read the flag before computing and route a soft batch to the dense kernels, as
+        # forward() does; later steps enqueue without a host sync and the Trainer reads the sticky
+        # flag periodically; dense_input=True goes straight to the dense kernels
+        xp = m._x_ptr(self.ctx, x, self.dev)
         if grad_sync is None:
             _lib.check(self.ctx.lib.explainn_train_step(
                 self.ctx.handle, xp, y.data_ptr(), B, C.byref(self.ps), C.byref(self.gs),

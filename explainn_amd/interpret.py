@@ -57,7 +57,7 @@ def _get_outs_preds(exp_model, Xs, batch_size=100):
     outputs = np.zeros((len(Xs), U), dtype=np.float16)
     predictions = np.zeros((len(Xs), T), dtype=np.float16)
     Xs = _as_tensor(Xs)
-    with torch.no_grad():
+    with torch.no_grad(), exp_model.eval_cache():
         for i, xb in _batches(Xs, batch_size):
             outs = exp_model.linears(xb.to(dev))
             outputs[i:i + len(xb)] = outs.cpu().numpy()
@@ -75,7 +75,7 @@ def _get_acts_outs_preds(exp_model, data_loader):
     predictions = np.zeros((N, o["n_features"]), dtype=np.float16)
     dev = exp_model.final.weight.device
     idx = 0
-    with torch.no_grad():
+    with torch.no_grad(), exp_model.eval_cache():
         for Xs, _ in data_loader:
             Xs = Xs.to(dev)
             outs = exp_model.linears(Xs)
@@ -133,24 +133,27 @@ def filter_pwms(exp_model, Xs, idxs, rev_complement=False, batch_size=1024, site
     was_training = exp_model.training
     exp_model.eval()
     try:
-        unit_max = torch.zeros(U, device=dev, dtype=torch.float32)
-        for i, xb in _batches(Xs, batch_size):
-            exp_model.filter_act_max(xb.to(dev), unit_max, select[i:i + len(xb)])
-        # interpret.py:373: 0.5 * amax of a float16 array stays float16
-        thresholds = (0.5 * unit_max.cpu().numpy().astype(np.float16)).astype(np.float16)
-        thr_dev = torch.from_numpy(thresholds.astype(np.float32)).to(dev)
-        site_total = torch.zeros(U, device=dev, dtype=torch.int32)
-        pfm = torch.zeros(U, k, 4, device=dev, dtype=torch.int32)
-        hit = np.zeros((N, U), dtype=bool)
-        # forward strand first, then the reverse strand (interpret.py:385-429); a batch never
-        # straddles the two halves, so site ranks follow the reference's order
-        bounds = [(0, half)] + ([(half, N)] if rev_complement else [])
-        for lo, hi in bounds:
-            for i in range(lo, hi, batch_size):
-                j = min(i + batch_size, hi)
-                h = exp_model.filter_sites(Xs[i:j].to(dev), thr_dev, site_total, pfm, select[i:j],
-                                           site_cap=site_cap, want_hit=True)
-                hit[i:j] = h.cpu().numpy().astype(bool)
+        with exp_model.eval_cache():
+            unit_max = torch.zeros(U, device=dev, dtype=torch.float32)
+            for i, xb in _batches(Xs, batch_size):
+                exp_model.filter_act_max(xb.to(dev), unit_max, select[i:i + len(xb)])
+            # interpret.py:373: 0.5 * amax of a float16 array stays float16
+            thresholds = (0.5 * unit_max.cpu().numpy().astype(np.float16)).astype(np.float16)
+            thr_dev = torch.from_numpy(thresholds.astype(np.float32)).to(dev)
+            site_total = torch.zeros(U, device=dev, dtype=torch.int32)
+            pfm = torch.zeros(U, k, 4, device=dev, dtype=torch.int32)
+            hit = np.zeros((N, U), dtype=bool)
+            # forward strand first, then the reverse strand (interpret.py:385-429); a batch never
+            # straddles the two halves, so site ranks follow the reference's order
+            bounds = [(0, half)] + ([(half, N)] if rev_complement else [])
+            for lo, hi in bounds:
+                for i in range(lo, hi, batch_size):
+                    j = min(i + batch_size, hi)
+                    h = exp_model.filter_sites(Xs[i:j].to(dev), thr_dev, site_total, pfm, select[i:j],
+                                               site_cap=site_cap, want_hit=True)
+                    hit[i:j] = h.cpu().numpy().astype(bool)
+        if exp_model.validate_input:
+            exp_model.check_input()
     finally:
         exp_model.train(was_training)
     return {"thresholds": thresholds, "pfm": pfm.cpu().numpy().astype(np.int64),

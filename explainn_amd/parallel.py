@@ -33,8 +33,14 @@ def broadcast_parameters(model, src=0):
     """Make every rank start from rank `src`'s parameters and BatchNorm buffers."""
     if world() == 1:
         return
-    for t in list(model.parameters()) + list(model.buffers()):
+    tensors = list(model.parameters()) + list(model.buffers())
+    for t in tensors:
         dist.broadcast(t.data, src)
+    # the broadcast wrote through `.data`, which torch's version counters do not see: tell the
+    # model (cached eval tables, explainn_params.version) that the values moved
+    torch.autograd.graph.increment_version(tensors)
+    if hasattr(model, "invalidate"):
+        model.invalidate()
 
 
 def average_gradients(flat):

@@ -50,7 +50,9 @@ def predict(model, Xs, batch_size=100, apply_sigmoid=False):
         data = torch.as_tensor(Xs_np, dtype=torch.float32)
     chunk = max(int(batch_size), _CHUNK)
     out = np.empty((len(data), model._options["n_features"], 4))
-    with torch.no_grad():
+    # the folded eval tables are built once for the whole loop (nothing writes parameters here);
+    # input validation is settled by ONE read of the sticky device flag after the last pass
+    with torch.no_grad(), model.eval_cache():
         for i in range(0, len(data), chunk):
             xb = data[i:i + chunk].to(device)
             if as_codes:
@@ -60,6 +62,8 @@ def predict(model, Xs, batch_size=100, apply_sigmoid=False):
             # numpy's float32 mean of two values is (a + b) / 2 in float32, as here
             both = torch.stack((fwd, rev, (fwd + rev) / 2, torch.maximum(fwd, rev)), dim=2)
             out[i:i + both.shape[0]] = both.cpu().numpy()
+    if model.validate_input:
+        model.check_input()
     if apply_sigmoid:
         out = torch.sigmoid(torch.Tensor(out)).numpy()
     return out

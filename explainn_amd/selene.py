@@ -8,6 +8,7 @@ of the two losses `get_loss` returns and the model is `explainn_amd.ExplaiNN`, t
 forward + loss + backward is ONE C-ABI call (`StepEngine`), gradients land in a flat buffer, and
 with torch.distributed initialised that buffer is all-reduced once per step.
 """
+import contextlib
 import copy
 import logging
 import os
@@ -226,6 +227,14 @@ class Trainer(object):
         """Average loss + all predictions/targets over a data set (selene/__init__.py:310-342)."""
         self.model.eval()
         batch_losses, all_predictions, all_targets = [], [], []
+        cache = self.model.eval_cache() if isinstance(self.model, ExplaiNN) else contextlib.nullcontext()
+        with cache:
+            out = self._evaluate_batches(which_data, batch_losses, all_predictions, all_targets)
+        if self.use_cuda and isinstance(self.model, ExplaiNN) and self.model.validate_input:
+            self._check_input_flags()
+        return out
+
+    def _evaluate_batches(self, which_data, batch_losses, all_predictions, all_targets):
         for inputs, targets in iter(self.data_loaders[which_data]):
             # a device-resident loader (loader.CodesLoader) yields views of a staging ring: cloned
             # on the device and brought to the host ONCE after the loop; host batches are kept as is

@@ -230,6 +230,15 @@ int explainn_stage_count(void);
 const char* explainn_stage_name(int i);
 int explainn_stage_times(explainn_ctx* ctx, float* us, int cap);
 
+/* Test aid for the built-in dropout generator (architectures/__init__.py:92 nn.Dropout(0.3); the
+ * reference exposes no mask either -- torch draws it inside the op).  After a train-mode forward
+ * of B sequences, copies the per-(unit, sequence) 100-bit words "pre-activation > 0 AND kept by
+ * dropout" the backward will use into out: device, uint32 (U, B, 4), channel r = bit (r & 31) of
+ * word r >> 5.  With BatchNorm2's weight = 0 and bias > 0 every pre-activation is positive and the
+ * words ARE the keep mask (tests/test_gpu_parity.py measures its rate, scaling and independence
+ * that way).  EXPLAINN_E_STATE without a train forward of that batch size in flight. */
+int explainn_debug_keep_bits(explainn_ctx* ctx, int B, uint32_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -434,23 +434,129 @@ def test_soft_input_takes_the_dense_path():
     m3(torch.from_numpy(xo).cuda())
 
 
-def test_builtin_dropout_rate_and_scaling():
-    """The counter-based generator drops ~30 % of the hidden activations and rescales by 1/0.7:
-    with all-positive pre-activations the kept fraction shows up directly in the bit mask, and
-    the mean logit over many units matches the no-dropout forward in expectation."""
-    U, k, L, T, B = 16, 19, 200, 1, 256
-    sd = orc.random_state_dict(U, k, L, T, seed=1, perturb=False)
-    x = torch.from_numpy(orc.random_onehot(B, L, seed=2)).cuda()
+def test_step_engine_takes_soft_input_like_forward():
+    """The fused step (StepEngine, what Trainer uses) follows the model's validation schedule: a
+    soft fp32 batch on the first steps is routed to the dense kernels, as forward() does (the
+    reference accepts any float input, architectures/__init__.py:111), and dense_input=True goes
+    there without validation."""
+    from explainn_amd.engine import StepEngine
+    U, k, L, T, B = 4, 9, 60, 2, 33
+    sd = orc.random_state_dict(U, k, L, T, seed=61)
+    rng = np.random.default_rng(62)
+    x = rng.dirichlet(np.ones(4) * 0.4, size=(B, L)).transpose(0, 2, 1).astype(np.float32)
+    x = np.ascontiguousarray(x)
+    y = (rng.random((B, T)) > 0.5).astype(np.float32)
+    ref_logits, ref_loss, ref_grads, _ = _oracle_step(sd, x, y)
+    for dense in (None, True):
+        m = _model(sd, U, k, L, T).train()
+        m.dropout_p = 0.0
+        m.dense_input = dense
+        eng = StepEngine(m, B, loss="binary")
+        for _ in range(3):                      # steps 1-2 validate, step 3 runs on the remembered route
+            m.load_state_dict({key: torch.from_numpy(np.array(v)) for key, v in sd.items()})
+            logits, loss = eng.step(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda())
+            _close(_np(logits), ref_logits, what="soft step logits (dense_input=%s)" % dense)
+            _close(loss.item(), ref_loss, tol=1e-5, what="loss")
+            _check_grads(zip([n for n, _ in m.named_parameters()], eng.views), ref_grads, "soft step ")
+
+
+def _keep_mask_of_last_forward(m, B):
+    """(U, B, 100) bool: the kept-bits words of the train forward in flight (explainn_debug_keep_bits)."""
+    import ctypes as C
+    U = m._options["cnn_units"]
+    ctx = m._rt.ctx
+    words = torch.empty(U, B, 4, dtype=torch.int32, device="cuda")
+    from explainn_amd import _lib
+    _lib.check(ctx.lib.explainn_debug_keep_bits(
+        ctx.handle, B, words.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    w = words.cpu().numpy().view(np.uint32)
+    bits = np.unpackbits(w.view(np.uint8).reshape(U, B, 16), axis=2, bitorder="little")
+    return bits[:, :, :100].astype(bool)
+
+
+def _corr(a, b):
+    a = a.astype(np.float64).ravel() - a.mean(); b = b.astype(np.float64).ravel() - b.mean()
+    return float((a * b).mean() / np.sqrt((a * a).mean() * (b * b).mean()))
+
+
+def test_builtin_dropout_generator_statistics():
+    """The built-in generator is what bench.py times and Trainer trains with (nn.Dropout(0.3),
+    architectures/__init__.py:92).  With BatchNorm2's weight 0 and bias 1 every pre-activation is
+    1 > 0, so the stored "relu' > 0 and kept" bits ARE the keep mask.  Measured over 3 seeds at
+    U = 32, B = 1024 (3.3 M draws each):
+      * keep rate 0.7 (exactly 1 - 19661/65536) overall, per channel, per sequence, per unit;
+      * no pairwise correlation between neighbouring channels (incl. the two 16-bit halves of one
+        generator word and consecutive generator states), neighbouring sequences, sequences 16 and
+        64 apart (the kernel's lane / tile strides), neighbouring units, and consecutive seeds;
+      * scaling: replaying the extracted mask through the keep_mask path -- the path the
+        reference's own masks pin, 1/(1-p) scaling included -- gives the same logits.
+    Every bound is k sigma of the estimator with k chosen for the number of simultaneous tests
+    (family-wise false-alarm rate < 1e-3)."""
+    U, k, L, T, B = 32, 19, 200, 1, 1024
+    sd = orc.random_state_dict(U, k, L, T, seed=5, perturb=False)
+    sd["linears.7.weight"] = np.zeros_like(sd["linears.7.weight"])
+    sd["linears.7.bias"] = np.ones_like(sd["linears.7.bias"])
+    x = torch.from_numpy(orc.random_onehot(B, L, seed=6)).cuda()
     m = _model(sd, U, k, L, T).train()
-    torch.manual_seed(0)
+    p_keep = 1.0 - 19661.0 / 65536.0
+    var = p_keep * (1 - p_keep)
+    masks, logits = [], []
+    torch.manual_seed(1234)
     with torch.no_grad():
-        a = m(x)
-        b = m(x)
-    assert not torch.equal(a, b), "two dropout draws must differ"
-    torch.manual_seed(0)
+        for _ in range(3):
+            logits.append(m(x).clone())
+            masks.append(_keep_mask_of_last_forward(m, B))
+    assert not np.array_equal(masks[0], masks[1]) and not np.array_equal(masks[1], masks[2])
+
+    def rate_check(what, values, n_per, k_sigma):
+        z = np.abs(values - p_keep).max() / np.sqrt(var / n_per)
+        record_margin("dropout keep rate, " + what, z, k_sigma)
+        assert z < k_sigma, "%s: keep rate off by %.2f sigma (bound %.1f)" % (what, z, k_sigma)
+
+    def corr_check(what, c, n_samples, k_sigma):
+        z = abs(c) * np.sqrt(n_samples)
+        record_margin("dropout correlation, " + what, z, k_sigma)
+        assert z < k_sigma, "%s: correlation %.2e = %.2f sigma (bound %.1f)" % (what, c, z, k_sigma)
+
+    for s_i, M in enumerate(masks):
+        tag = "seed %d " % s_i
+        rate_check(tag + "overall", np.array([M.mean()]), M.size, 4.0)
+        rate_check(tag + "per channel", M.mean(axis=(0, 1)), U * B, 4.6)
+        rate_check(tag + "per sequence", M.mean(axis=(0, 2)), U * 100, 5.0)
+        rate_check(tag + "per unit", M.mean(axis=(1, 2)), B * 100, 4.4)
+        for r in range(99):                                   # neighbouring channels, pair by pair
+            corr_check(tag + "channels r,r+1", _corr(M[:, :, r], M[:, :, r + 1]), U * B, 4.8)
+        for d in (1, 2, 4):
+            corr_check(tag + "channels r,r+%d pooled" % d, _corr(M[:, :, :-d], M[:, :, d:]), U * B * (100 - d), 4.2)
+        for d in (1, 16, 64):
+            corr_check(tag + "sequences b,b+%d" % d, _corr(M[:, :-d, :], M[:, d:, :]), U * (B - d) * 100, 4.2)
+        corr_check(tag + "units u,u+1", _corr(M[:-1], M[1:]), (U - 1) * B * 100, 4.2)
+        # three-way parity of one lane's consecutive draws (an xorshift stream is GF(2)-linear)
+        par = M[:, :, 0:96:3] ^ M[:, :, 1:96:3] ^ M[:, :, 2:96:3]
+        p3 = 0.5 * (1 - (1 - 2 * p_keep) ** 3)
+        z = abs(par.mean() - p3) / np.sqrt(p3 * (1 - p3) / par.size)
+        record_margin("dropout parity of three consecutive draws", z, 4.2)
+        assert z < 4.2, z
+    for a, b_ in ((0, 1), (1, 2)):
+        corr_check("consecutive seeds", _corr(masks[a], masks[b_]), masks[a].size, 4.2)
+    # scaling: the generator path and the keep-mask path (pinned to the reference by the drop/*
+    # golden vectors) must be one computation
+    keep = np.ascontiguousarray(np.transpose(masks[2], (1, 0, 2)).reshape(B, 100 * U)).astype(np.uint8)
+    m.set_dropout_mask(torch.from_numpy(keep))
     with torch.no_grad():
-        a2 = m(x)
-    assert torch.equal(a, a2), "same torch seed -> same mask"
+        replay = m(x)
+    assert torch.equal(replay, logits[2]), float((replay - logits[2]).abs().max())
+    # same torch seed -> same masks; the accessor refuses when no train forward is in flight
+    torch.manual_seed(1234)
+    with torch.no_grad():
+        again = m(x)
+    assert torch.equal(again, logits[0])
+    assert np.array_equal(_keep_mask_of_last_forward(m, B), masks[0])
+    m.eval()
+    with torch.no_grad():
+        m(x)
+    with pytest.raises(Exception, match="train-mode forward"):
+        _keep_mask_of_last_forward(m, B)
 
 
 @pytest.mark.parametrize("T,kind", [(1, "binary"), (3, "linear"), (6, "binary"), (50, "binary"),
@@ -657,48 +763,15 @@ def test_smaller_batch_after_larger_one_on_the_same_context():
             _close_rel(_np(v).reshape(ref_grads[key].shape), ref_grads[key], tol=GRAD_TOL_ORACLE, what="grad " + key)
 
 
-def test_graph_replay_equals_direct_launches():
-    """With EXPLAINN_GRAPH=1, on a non-default stream, explainn_train_step captures itself into a
-    hipGraph once its arguments have repeated three times and replays it afterwards (seed through
-    device memory).
-    Every step must equal, bit for bit, the same step issued as direct launches on the default
-    stream -- dropout on, so a stale seed would show -- and a changed argument must fall back."""
-    import os
-    from explainn_amd.engine import StepEngine
-    g = Golden("mid_u8_k19_L200")
-    x = torch.from_numpy(g.onehot()).cuda()
-    y = torch.from_numpy(g.targets().astype(np.float32)).cuda()
-    engines = []
-    os.environ["EXPLAINN_GRAPH"] = "1"                  # opt-in (off by default: no faster, DESIGN.md)
-    for _ in range(2):
-        m = _model(g.sd(), g.U, g.k, g.L, g.T).train()
-        m.dropout_p = 0.3
-        engines.append(StepEngine(m, g.B, loss=g.loss_kind))
-    direct, graphed = engines
-    side = torch.cuda.Stream()
-    x2 = x.clone()
-    for it in range(9):
-        xin = x2 if it == 6 else x                      # step 6: another input buffer -> direct fallback
-        a = direct.step(xin, y, seed=100 + it)
-        ref = (a[0].clone(), a[1].clone(), direct.flat_grad.clone())
-        torch.cuda.synchronize()
-        with torch.cuda.stream(side):
-            b = graphed.step(xin, y, seed=100 + it)
-        side.synchronize()
-        assert torch.equal(ref[0], b[0]) and torch.equal(ref[1], b[1]), it
-        assert torch.equal(ref[2], graphed.flat_grad), it
-    os.environ.pop("EXPLAINN_GRAPH", None)
-    # BatchNorm buffers advanced identically (they are updated inside the captured kernels)
-    for (ka, va), (kb, vb) in zip(direct.model.state_dict().items(), graphed.model.state_dict().items()):
-        assert torch.equal(va, vb), ka
-
-
 def test_eval_tables_follow_parameter_changes():
-    """The eval entry points keep their folded tables (filter LUTs, BatchNorm folds, FC1 fragments)
-    between calls and rebuild them when explainn_params.version moves.  Every way the values can
-    change must move it: an in-place torch update, a train-mode step of this package (BatchNorm
-    buffers written through raw pointers), the fused Adam launch, load_state_dict, and a
-    re-assigned Parameter."""
+    """Inside an eval_cache() scope the eval entry points keep their folded tables (filter LUTs,
+    BatchNorm folds, FC1 fragments) between calls and rebuild them when explainn_params.version
+    moves.  Every way the values can change that torch can see must move it: an in-place torch
+    update, a train-mode step of this package (BatchNorm buffers written through raw pointers),
+    the fused Adam launch, load_state_dict, a re-assigned Parameter; a write through `.data`
+    (selene/__init__.py:294 `final.weight.data.clamp_(0)`), which torch's version counters do NOT
+    see, needs invalidate() inside a scope -- and nothing at all outside one, where every call
+    rebuilds the tables."""
     from explainn_amd import get_optimizer
     U, k, L, T, B = 4, 9, 60, 2, 24
     sd = orc.random_state_dict(U, k, L, T, seed=71)
@@ -706,42 +779,94 @@ def test_eval_tables_follow_parameter_changes():
     x = orc.random_onehot(B, L, seed=72, n_frac=0.02)
     xt = torch.from_numpy(x).cuda()
 
-    def check(what):
+    def check(what, scoped=True):
         cur = {key: _np(v) for key, v in m.state_dict().items()}
         m.eval()
         with torch.no_grad():
             a = m(xt)
-            b = m(xt)                                 # second call: cached tables
+            b = m(xt)                                 # second call: cached tables inside a scope
         assert torch.equal(a, b)
         _close(_np(a), orc.forward(cur, x), what=what)
 
-    check("initial")
+    with m.eval_cache():
+        check("initial")
+        with torch.no_grad():
+            m.linears[0].weight.mul_(1.5)                 # in-place torch op
+            m.linears[7].running_var.add_(0.3)
+        check("after in-place updates")
+        m.train()
+        m.dropout_p = 0.0
+        out = m(xt)                                       # train forward: buffers move, tables overwritten
+        out.sum().backward()
+        check("after a train-mode forward/backward")
+        opt = get_optimizer(m.parameters(), 0.01)
+        m.train()
+        torch.nn.functional.binary_cross_entropy_with_logits(m(xt), torch.ones(B, T).cuda()).backward()
+        opt.step()                                        # fused Adam: raw-pointer update
+        check("after a fused Adam step")
+        m.load_state_dict({key: torch.from_numpy(np.array(v)) for key, v in sd.items()})
+        check("after load_state_dict")
+        m.final.weight = torch.nn.Parameter(m.final.weight.detach() * 2)
+        check("after re-assigning a Parameter")
+        # a `.data` write inside the scope: invisible to torch's counters, so the owner of the scope
+        # says so
+        m.final.weight.data.clamp_(0)
+        m.linears[0].weight.data[1] += 0.25
+        m.invalidate()
+        check("after .data writes + invalidate()")
+    # outside a scope nothing is cached: `.data` writes need no announcement
+    check("outside a scope")
+    m.final.weight.data.mul_(-1.0)
+    m.linears[0].weight.data[0] -= 0.5
+    m.linears[7].running_mean.data.add_(0.1)
+    check("after .data writes outside a scope")
+    # nested scopes and a scope opened after writes made outside it
+    m.linears[1].weight.data.mul_(1.1)
+    with m.eval_cache():
+        check("scope opened after a .data write")
+        with m.eval_cache():
+            check("nested scope")
+
+
+def test_input_validation_schedule():
+    """validate_input=True: the first two forwards read the validation flag before computing (a
+    soft batch is routed to the dense kernels and the model keeps validating per call from then
+    on); later forwards of a model that has only seen one-hot input enqueue without a host sync and
+    the sticky flag is read by check_input() / every 64th call: a soft batch then raises instead of
+    passing silently.  'always' routes every batch."""
+    U, k, L, T, B = 3, 9, 60, 1, 16
+    sd = orc.random_state_dict(U, k, L, T, seed=91)
+    xo = orc.random_onehot(B, L, seed=92)
+    rng = np.random.default_rng(93)
+    xs = rng.random((B, 4, L)).astype(np.float32)
+    xs /= xs.sum(1, keepdims=True)
+    xo_t, xs_t = torch.from_numpy(xo).cuda(), torch.from_numpy(xs).cuda()
+    m = _model(sd, U, k, L, T).eval()
     with torch.no_grad():
-        m.linears[0].weight.mul_(1.5)                 # in-place torch op
-        m.linears[7].running_var.add_(0.3)
-    check("after in-place updates")
-    m.train()
-    m.dropout_p = 0.0
-    out = m(xt)                                       # train forward: buffers move, tables overwritten
-    out.sum().backward()
-    check("after a train-mode forward/backward")
-    opt = get_optimizer(m.parameters(), 0.01)
-    m.train()
-    torch.nn.functional.binary_cross_entropy_with_logits(m(xt), torch.ones(B, T).cuda()).backward()
-    opt.step()                                        # fused Adam: raw-pointer update
-    check("after a fused Adam step")
-    m.load_state_dict({key: torch.from_numpy(np.array(v)) for key, v in sd.items()})
-    check("after load_state_dict")
-    m.final.weight = torch.nn.Parameter(m.final.weight.detach() * 2)
-    check("after re-assigning a Parameter")
+        for _ in range(4):
+            _close(_np(m(xo_t)), orc.forward(sd, xo), what="one-hot, deferred validation")
+        m.check_input()                               # nothing flagged so far
+        m(xs_t)                                       # call 5: not validated before computing ...
+        with pytest.raises(ValueError, match="not one-hot"):
+            m.check_input()                           # ... but reported here
+        m.check_input()                               # the flag was cleared by the read
+        m.validate_input = "always"
+        _close(_np(m(xs_t)), orc.forward(sd, xs), what="soft batch under validate_input='always'")
+        _close(_np(m(xo_t)), orc.forward(sd, xo), what="one-hot batch after it")
+    m2 = _model(sd, U, k, L, T).eval()
+    with torch.no_grad():
+        _close(_np(m2(xs_t)), orc.forward(sd, xs), what="soft batch on the first call")
+        for _ in range(3):                            # a model that met soft input keeps routing per call
+            _close(_np(m2(xs_t)), orc.forward(sd, xs), what="soft batch on later calls")
+            _close(_np(m2(xo_t)), orc.forward(sd, xo), what="one-hot between soft batches")
 
 
-def test_fc_bf16_piece_products_are_fp32_accurate(monkeypatch):
+def test_fc_bf16_piece_products_are_fp32_accurate():
     """fc_fwd runs on the bf16 matrix core with BOTH fp32 operands split exactly into three bf16
     pieces and all nine piece products accumulated in fp32.  Claim under test: that is
-    an fp32 computation, not a reduced-precision one -- against the fp64 oracle the unit outputs are
-    as close as those of the fp32-MFMA form of the same contraction (the single-launch eval kernel,
-    v_mfma_f32_16x16x4_f32), at rounding level (a bf16-input GEMM would be off by ~1e-3)."""
+    an fp32 computation, not a reduced-precision one -- against the fp64 oracle the unit outputs
+    are at fp32 rounding level (round 2 measured 3.3e-7 of scale for this form and 4.1e-7 for the
+    fp32-MFMA form of the same contraction; a bf16-input GEMM would be off by ~1e-3)."""
     U, k, L, T, B = 24, 19, 200, 1, 256
     sd = orc.random_state_dict(U, k, L, T, seed=77)
     x = orc.random_onehot(B, L, seed=78)
@@ -749,45 +874,8 @@ def test_fc_bf16_piece_products_are_fp32_accurate(monkeypatch):
     m = _model(sd, U, k, L, T).eval()
     xt = torch.from_numpy(x).cuda()
     with torch.no_grad():
-        monkeypatch.delenv("EXPLAINN_EVAL_FUSED", raising=False)
         bf = _np(m.linears(xt.repeat(1, U, 1)))
-        monkeypatch.setenv("EXPLAINN_EVAL_FUSED", "1")
-        f32 = _np(m.linears(xt.repeat(1, U, 1)))
-    monkeypatch.delenv("EXPLAINN_EVAL_FUSED", raising=False)
     scale = max(1.0, np.abs(ref).max())
-    e_bf, e_f32 = np.abs(bf - ref).max() / scale, np.abs(f32 - ref).max() / scale
-    print("unit outputs vs fp64: bf16 nine-piece form %.2e, fp32 MFMA form %.2e" % (e_bf, e_f32))
-    assert e_bf <= 3e-6 and e_f32 <= 3e-6, (e_bf, e_f32)
-    assert e_bf <= 2 * e_f32 + 2e-7, (e_bf, e_f32)
-
-
-def test_single_launch_eval_kernel(monkeypatch):
-    """EXPLAINN_EVAL_FUSED=1: the eval forward as pack + ONE launch (filter bank -> pooling -> exp
-    -> FC -> combiner with the pooled activations in LDS, partial logits combined by the last
-    workgroup of each sequence tile).  Same numbers as the default path to rounding (its FC runs on
-    the fp32 matrix core, the default one as nine exact bf16 piece products: another summation
-    order; the combiner sums units in another order) and as the golden vectors; deterministic from
-    call to call."""
-    for name in ("small_u8_k19", "mid_u8_k19_L200", "tiny_u3_k5_N", "c1_u100_k19_L200"):
-        g = Golden(name)
-        m = _model(g.sd(), g.U, g.k, g.L, g.T).eval()
-        x = torch.from_numpy(g.onehot()).cuda()
-        with torch.no_grad():
-            monkeypatch.delenv("EXPLAINN_EVAL_FUSED", raising=False)
-            ref_logits, ref_outs = m(x), m.linears(x.repeat(1, g.U, 1))
-            monkeypatch.setenv("EXPLAINN_EVAL_FUSED", "1")
-            a, b = m(x), m(x)
-            outs = m.linears(x.repeat(1, g.U, 1))
-        assert torch.equal(a, b), name
-        _close(_np(outs), _np(ref_outs), tol=2e-6, what=name + " fused vs default unit outputs")
-        _close(_np(a), _np(ref_logits), tol=2e-6, what=name + " fused vs default logits")
-        _close(_np(a), g.z["eval/logits"], what=name + " fused eval logits")
-    monkeypatch.delenv("EXPLAINN_EVAL_FUSED", raising=False)
-    # many tasks: the kernel exports the unit outputs and the combiner GEMM follows
-    U, k, L, T, B = 37, 19, 61, 50, 70
-    sd = orc.random_state_dict(U, k, L, T, seed=U + L)
-    x = orc.random_onehot(B, L, seed=4, n_frac=0.02)
-    m = _model(sd, U, k, L, T).eval()
-    monkeypatch.setenv("EXPLAINN_EVAL_FUSED", "1")
-    with torch.no_grad():
-        _close(_np(m(torch.from_numpy(x).cuda())), orc.forward(sd, x), what="fused eval, T = 50")
+    e_bf = np.abs(bf - ref).max() / scale
+    record_margin("abs unit outputs vs fp64 (bf16 nine-piece fc_fwd)", e_bf, 3e-6)
+    assert e_bf <= 3e-6, e_bf

@@ -315,14 +315,20 @@ def test_c5_shard_shape_against_fp64_oracle():
     _shard_case(8, 600, 164, 1024, seed=41)
 
 
-def test_c5_unit_count_determinism_and_unit_permutation():
-    """U = 2000 (config C5) at B = 128: 2.7 GB-class scratch indexing (size_t offsets into ext /
-    dy / partials) and a grid of 2000 units.  Two identical steps are bitwise identical, and
-    permuting the units (every per-unit parameter row together with its column of final.weight)
-    permutes every per-unit gradient the same way and leaves the logits unchanged to 1e-4."""
+@pytest.mark.parametrize("Bc", [128, 1024])
+def test_c5_unit_count_determinism_and_unit_permutation(Bc):
+    """U = 2000 (config C5): a grid of 2000 units and size_t offsets into ext / dy / partials.
+    At Bc = 1024 this is the FULL per-GPU shard of config C5 (U = 2000, L = 600, T = 164,
+    B = 1024; 2.7 GB of scratch): ext / dy are 2000 x 83 x 1088 x 4 B = 722 MB each and the
+    passA partials U x ACH x 100 x NS floats, so element offsets times 4 exceed 2^31 bytes in
+    several arrays -- the combination no oracle-sized test reaches.  Two identical steps are
+    bitwise identical, and permuting the units (every per-unit parameter row together with its
+    column of final.weight) permutes every per-unit gradient the same way and leaves the logits
+    unchanged to 1e-4: a unit whose indexing wrapped or aliased another's scratch would break
+    either property."""
     from explainn_amd import ExplaiNN
     from explainn_amd.engine import StepEngine
-    Uc, Lc, Tc, Bc = 2000, 600, 164, 128
+    Uc, Lc, Tc = 2000, 600, 164
     torch.manual_seed(51)
     m = ExplaiNN(Uc, K, Lc, Tc).cuda().train()
     m.dropout_p = 0.0

@@ -13,7 +13,8 @@ for B in (100, 1024, 4096):
     x = torch.zeros(B, 4, L).scatter_(1, idx[:, None, :], 1.0).to(dev)
     codes = idx.to(torch.uint8).to(dev)
     for name, inp in (("one-hot", x), ("codes", codes), ("codes rc", BaseCodes(codes, True))):
-        with torch.no_grad():
+        # the folded tables are reused across calls only inside an eval_cache() scope (as predict() does)
+        with torch.no_grad(), m.eval_cache():
             for _ in range(10): m(inp)
             torch.cuda.synchronize(); t0 = time.perf_counter(); K = 200
             for _ in range(K): m(inp)

@@ -1,0 +1,177 @@
+// Vector / LDS issue-rate probe for gfx950: how many wave-instructions per
+// cycle does ONE SIMD issue when 1, 2, 4 or 5 waves are resident on it, on every CU at once?
+// DESIGN.md section 5 priced the "issue roof" of the gather kernels at 4 clk per wave-instruction per
+// SIMD; MI355X_MICROARCH.md says a wave64 VALU instruction takes 2 cycles on the SIMD-32 and that
+// ONE wave alone sustains one per 4.  This settles which holds for the instruction mixes the
+// kernels are made of.
+//
+//   hipcc -O3 --offload-arch=gfx950 tools/issue_rate.hip -o gpurun_out/issue_rate && gpurun_out/issue_rate
+//
+// Geometry: workgroups of 256 threads (4 waves, one per SIMD: waves of a workgroup are dealt to the
+// SIMDs cyclically), W workgroups per CU forced by the LDS each declares (floor(160 KiB / W)), grid
+// = 256 CUs x W, so every SIMD of the chip holds exactly W waves for the whole run.  Each wave runs
+// REPS x UNROLL instructions of the mix on independent registers between two s_memtime stamps.
+// Reported: per-SIMD rate = W x instructions per wave / median wave cycles, and the clk per
+// wave-instruction that implies (the number bench.py's `issue_clk_per_inst` quotes).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { MIX_FMA, MIX_PK_FMA, MIX_PK_ADD, MIX_AND_OR, MIX_DS128, MIX_CONVPOOL, MIX_CONVBWD, MIX_EXP, MIX_COUNT };
+static const char* kMixName[MIX_COUNT] = {
+    "v_fma_f32", "v_pk_fma_f32", "v_pk_add_f32", "v_and_or_b32", "ds_read_b128 (16 rows)",
+    "conv_pool mix (bfe, and_or, ds128, 2 pk_add)", "conv_bwd mix (lshr, and_or, ds128, 2 pk_fma)",
+    "v_exp_f32"};
+// wave-instructions per inner-loop body of each mix (what the rate is counted in)
+static const int kMixInsts[MIX_COUNT] = {32, 32, 32, 32, 16, 40, 40, 32};
+
+struct Rec { unsigned long long cyc, t0, t1; };
+
+template <int MIX>
+__global__ __launch_bounds__(256) void issue_probe(Rec* rec, float* sink, int reps, int lds_floats) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    // a 16-row x 16-byte table at LDS offset 0 (conflict-free: 16 distinct rows = 64 distinct banks)
+    for (int i = tid; i < 1024; i += 256) lds[i] = (float)i * 1e-3f;
+    __syncthreads();
+    float a[8]; f32x2 p[8];
+    for (int i = 0; i < 8; ++i) { a[i] = (float)(lane + i); p[i] = f32x2{(float)i, (float)(lane - i)}; }
+    float x = 1.0001f, y = 0.9999f;
+    f32x2 px = {1.0001f, 0.9999f}, py = {0.5f, 0.25f};
+    unsigned bits = (unsigned)lane * 0x9E3779B9u, m = 0xf0u, base = 0u;
+    unsigned u[8];
+    for (int i = 0; i < 8; ++i) u[i] = bits + i;
+    f32x4 row[4] = {};
+    // the table address of lane l: row (hash & 15) -> byte offset 16 * row, all 16 rows in use
+    unsigned addr[4];
+    for (int i = 0; i < 4; ++i) addr[i] = (((unsigned)lane * 7u + i * 5u) & 15u) * 16u;
+    __builtin_amdgcn_s_barrier();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int r = 0; r < reps; ++r) {
+        if (MIX == MIX_FMA) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(y));
+        } else if (MIX == MIX_PK_FMA) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[i]) : "v"(px), "v"(py));
+        } else if (MIX == MIX_PK_ADD) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(px));
+        } else if (MIX == MIX_AND_OR) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(m), "v"(base));
+        } else if (MIX == MIX_EXP) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+        } else if (MIX == MIX_DS128) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(row[i]) : "v"(addr[i]));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        } else if (MIX == MIX_CONVPOOL) {
+            // conv_pool's inner body per tap pair and unit quad: one field extract of the packed codes,
+            // the table address by and-or, one 16-byte row read, two packed adds into the four sums
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                unsigned f, ad;
+                asm volatile("v_bfe_u32 %0, %1, %2, 8" : "=v"(f) : "v"(bits), "v"((unsigned)(k * 3)));
+                asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(ad) : "v"(f), "v"(m), "v"(base));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(row[k & 3]) : "v"(ad));
+                if ((k & 3) == 3) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[(2 * k) & 7]) : "v"(px));
+                asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[(2 * k + 1) & 7]) : "v"(py));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if (MIX == MIX_CONVBWD) {
+            // conv_bwd's body per (window, tap): a shift of the code word, the row address by and-or, one
+            // one-hot row read (16 bytes), two packed FMAs of the pooled gradient into the tap's sums
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                unsigned f, ad;
+                asm volatile("v_lshrrev_b32 %0, %1, %2" : "=v"(f) : "v"((unsigned)(2 * k)), "v"(bits));
+                asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(ad) : "v"(f), "v"(m), "v"(base));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(row[k & 3]) : "v"(ad));
+                if ((k & 3) == 3) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[(2 * k) & 7]) : "v"(px), "v"(py));
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[(2 * k + 1) & 7]) : "v"(py), "v"(px));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float out = row[0][0] + row[1][1] + row[2][2] + row[3][3];
+    for (int i = 0; i < 8; ++i) out += a[i] + p[i][0] + p[i][1] + (float)u[i];
+    sink[(size_t)blockIdx.x * 256 + tid] = out;
+    if (lane == 0) {
+        Rec& r = rec[(size_t)blockIdx.x * 4 + (tid >> 6)];
+        r.cyc = t1 - t0; r.t0 = t0; r.t1 = t1;
+    }
+}
+
+template <int MIX>
+static void run(int W, Rec* rec, float* sink, int reps) {
+    const int cus = 256, grid = cus * W;
+    // force W workgroups per CU: each declares floor(160 KiB / W) of LDS (W = 1: 160 KiB itself)
+    size_t lds = (size_t)(160 * 1024 / W) & ~(size_t)255;
+    if (lds < 4096) lds = 4096;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&issue_probe<MIX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float ms = 0.f;
+    for (int it = 0; it < 3; ++it) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(issue_probe<MIX>, dim3(grid), dim3(256), lds, 0, rec, sink, reps, (int)(lds / 4));
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        CK(hipGetLastError());
+        CK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    std::vector<Rec> h((size_t)grid * 4);
+    CK(hipMemcpy(h.data(), rec, h.size() * sizeof(Rec), hipMemcpyDeviceToHost));
+    std::vector<double> cyc;
+    unsigned long long tmin = ~0ull, tmax = 0;
+    for (auto& r : h) { cyc.push_back((double)r.cyc); tmin = std::min(tmin, r.t0); tmax = std::max(tmax, r.t1); }
+    std::sort(cyc.begin(), cyc.end());
+    const double insts = (double)reps * kMixInsts[MIX];
+    const double p50 = cyc[cyc.size() / 2], p90 = cyc[cyc.size() * 9 / 10];
+    // all W waves of a SIMD run the same stream at the same time: the SIMD issued W x insts in p50 cycles
+    printf("%-46s W=%d  wave cycles p50 %9.0f p90 %9.0f  -> %.3f wave-inst/clk/SIMD = %.2f clk per wave-inst  (event %.1f us, clock %.2f GHz)\n",
+           kMixName[MIX], W, p50, p90, W * insts / p50, p50 / (W * insts), ms * 1e3, p50 / (ms * 1e3) / 1e3);
+}
+
+int main() {
+    Rec* rec; float* sink;
+    CK(hipMalloc(&rec, (size_t)256 * 8 * 4 * sizeof(Rec)));
+    CK(hipMalloc(&sink, (size_t)256 * 8 * 256 * sizeof(float)));
+    const int reps = 2000;
+    const int Ws[] = {1, 2, 4, 5, 8};
+    for (int W : Ws) {
+        run<MIX_FMA>(W, rec, sink, reps);
+        run<MIX_PK_FMA>(W, rec, sink, reps);
+        run<MIX_PK_ADD>(W, rec, sink, reps);
+        run<MIX_AND_OR>(W, rec, sink, reps);
+        run<MIX_EXP>(W, rec, sink, reps);
+        run<MIX_DS128>(W, rec, sink, reps);
+        run<MIX_CONVPOOL>(W, rec, sink, reps);
+        run<MIX_CONVBWD>(W, rec, sink, reps);
+        printf("\n");
+    }
+    return 0;
+}

@@ -69,6 +69,14 @@ static void balance(const char* name, const std::vector<unsigned long long>& h, 
 }
 #endif
 
+// every launch starts from zeroed stamps: a wave that leaves before a stamp (passA's second wave
+// hands its tile over and returns) must read as "no stamp", not as the previous kernel's value
+static void clear_stamps() {
+    void* p = nullptr;
+    CK(hipGetSymbolAddress(&p, HIP_SYMBOL(g_stamps)));
+    CK(hipMemset(p, 0, sizeof(unsigned long long) << 20));
+}
+
 static void report(const char* name, int waves, int nst, float ms) {
     std::vector<unsigned long long> h((size_t)waves * 8);
     CK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_stamps), h.size() * 8));
@@ -109,18 +117,22 @@ int main() {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); float ms;
     for (int rep = 0; rep < 2; ++rep) {
         CK(hipMemset(fz, 0, 4));
+        clear_stamps();
         CK(hipEventRecord(e0));
         hipLaunchKernelGGL(qmom_kernel<26>, dim3(QCH, U, 1), dim3(64), 0, 0, ext, alpha, shift, qs0, S1p, S2p, n, Bs, B, QCH);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
         if (rep) report("qmom", QCH * U, 4, ms);
+        clear_stamps();
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((fc_fwd_bf_kernel<26, 2>), dim3(4, U), dim3(256), fc_fwd_bf_lds<26>(), 0, ext, alpha, shift, A2h, sh2, V2, bits, z, (const uint8_t*)nullptr, 19661u, 1.4285715f, 1u, 2u, fz, fz, fz, fz, fz, o, n, Bs, B, U, (const uint32_t*)nullptr, z12p);
+        hipLaunchKernelGGL((fc_fwd_bf_kernel<26, 2>), dim3(4, U), dim3(256), fc_fwd_bf_lds<26>(), 0, ext, alpha, shift, A2h, sh2, V2, bits, z, (const uint8_t*)nullptr, 19661u, 1.4285715f, 1u, 2u, fz, fz, fz, fz, fz, o, n, Bs, B, U, z12p);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
         if (rep) report("fc_fwd", 4 * U * 4, 5, ms);
+        clear_stamps();
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(passA_kernel<26>, dim3(ACH, U, 1), dim3(64 * PA_WAVES), 0, 0, ext, alpha, shift, dz, bits, EQp, Sep, n, Bs, B, ACH, pa_head_args{}, U);
+        hipLaunchKernelGGL((passA_kernel<26, false>), dim3(ACH, U, 1), dim3(64 * PA_WAVES), 0, 0, ext, alpha, shift, dz, bits, EQp, Sep, n, Bs, B, ACH, pa_head_args{}, U);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
         if (rep) report("passA", ACH * U * PA_WAVES, 4, ms);
+        clear_stamps();
         CK(hipEventRecord(e0));
         hipLaunchKernelGGL(passB_kernel<26>, dim3(4, U, 1), dim3(256), passB_lds<26>(), 0, ext, alpha, shift, dz, bits, Tt, M, k0p, mug, sig1, dy, S12p, n, Bs, B); // (tables passed as fragment-ordered stand-ins)
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
@@ -141,18 +153,22 @@ int main() {
         float* md = (float*)dalloc((size_t)U * 100 * n * 4 + 4096);
         size_t cps = (size_t)(NT * 16 + k * 5) * 16 + (size_t)(8 + 5) * 64 * 4;   // 8-window code tiles (convpool.hip: conv_pool_lds)
         for (int rep = 0; rep < 2; ++rep) {
+            clear_stamps();
             CK(hipEventRecord(e0));
             hipLaunchKernelGGL((conv_pool_kernel<19, 8, true>), dim3(16 * 4, U4 / 4), dim3(64), cps, 0, pk2, nmask, (const float4*)lut, Wt, alpha, U, ext, idx, n, Bs, PW, NW, 4);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
             if (rep) report("conv_pool", 16 * 4 * (U4 / 4), 3, ms);
+            clear_stamps();
             CK(hipEventRecord(e0));
             hipLaunchKernelGGL(conv_bwd_kernel<19>, dim3(8, U), dim3(64), (size_t)(PW + NW) * 256 + 128 + 64, 0, dy, idx, pk2, nmask, Dspp, U, n, Bs, PW, NW, (PW + NW) * 64, B);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
             if (rep) report("conv_bwd", 8 * U, 4, ms);
+            clear_stamps();
             CK(hipEventRecord(e0));
             hipLaunchKernelGGL(prep2_kernel<true>, dim3(U), dim3(1024), prep2_lds(n, NS), 0, fc1_w, sh2, sh2, sh2, md, md + U * 100, (int64_t*)nullptr, qs0, S1p, S2p, qbar, VC, A2, (float*)nullptr, sh2, sig2, n, NS, NK4Q, B, QCH, A2h, fc_ks32(NQ));
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
             if (rep) report("prep2", U * 16, 4, ms);
+            clear_stamps();
             CK(hipEventRecord(e0));
             hipLaunchKernelGGL(mid_fused_kernel, dim3(U), dim3(1024), mid_fused_lds(n), 0, EQp, Sep, A2, sh2, sig2, fc1_w, V2, sh2, qbar, VC, Tt, M, k0p, md, md, md, md, md, n, NS, NW16, B, ACH, 1.4285715f);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
