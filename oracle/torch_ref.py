@@ -39,7 +39,9 @@ def init_state(U, k, L, T, seed=0):
     return sd
 
 
-def forward(sd, x, training, p=0.3):
+def forward(sd, x, training, p=0.3, keep_mask=None):
+    """keep_mask: optional (B, 100U) 0/1 tensor replacing dropout's own draw (what nn.Dropout does
+    with its mask: multiply and rescale by 1/(1-p))."""
     U = sd["linears.0.weight"].shape[0]
 
     def bn(t, key):
@@ -50,18 +52,21 @@ def forward(sd, x, training, p=0.3):
     h = torch.exp(bn(h, "linears.1"))
     h = F.max_pool1d(h, 7, 7).flatten(1).unsqueeze(-1)
     h = F.conv1d(h, sd["linears.6.weight"], sd["linears.6.bias"], groups=U)
-    h = F.dropout(F.relu(bn(h, "linears.7")), p, training)
+    if keep_mask is not None and training:
+        h = F.relu(bn(h, "linears.7")) * keep_mask.to(h.dtype).unsqueeze(-1) / (1.0 - p)
+    else:
+        h = F.dropout(F.relu(bn(h, "linears.7")), p, training)
     h = F.conv1d(h, sd["linears.10.weight"], sd["linears.10.bias"], groups=U)
     h = F.relu(bn(h, "linears.11")).flatten(1)
     return F.linear(h, sd["final.weight"], sd["final.bias"])
 
 
-def train_step(sd, x, y, loss="binary", p=0.3):
+def train_step(sd, x, y, loss="binary", p=0.3, keep_mask=None):
     """train-mode forward + loss + backward; returns (loss, logits, grads dict)."""
     leaves = {k: sd[k].requires_grad_(True) for k in PARAMS}
     for v in leaves.values():
         v.grad = None
-    logits = forward(sd, x, True, p)
+    logits = forward(sd, x, True, p, keep_mask)
     lval = (F.binary_cross_entropy_with_logits(logits, y) if loss == "binary"
             else F.mse_loss(logits, y))
     lval.backward()

@@ -11,12 +11,18 @@
 // SIMDs cyclically), W workgroups per CU forced by the LDS each declares (floor(160 KiB / W)), grid
 // = 256 CUs x W, so every SIMD of the chip holds exactly W waves for the whole run.  Each wave runs
 // REPS x UNROLL instructions of the mix on independent registers between two s_memtime stamps.
-// Reported: per-SIMD rate = W x instructions per wave / median wave cycles, and the clk per
-// wave-instruction that implies (the number bench.py's `issue_clk_per_inst` quotes).
+// Every wave also records WHERE it ran (HW_ID: XCC, SE, CU, SIMD).  The report groups the waves by
+// SIMD and computes, per SIMD, (waves on it) x (instructions per wave) / (last end - first start):
+// the issue rate that SIMD actually delivered with the waves it actually held -- placement is the
+// dispatcher's, so the table is keyed by the resident-wave count that was OBSERVED (the LDS
+// declaration only caps it).  The clock is measured too (s_memtime ticks per 100 MHz s_memrealtime
+// tick), so "clk" is shader cycles.  Reported per (mix, waves per SIMD): median over SIMDs of
+// wave-instructions per clk, and its inverse -- the number bench.py quotes as `issue_clk_per_inst`.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <map>
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -30,9 +36,9 @@ static const char* kMixName[MIX_COUNT] = {
     "conv_pool mix (bfe, and_or, ds128, 2 pk_add)", "conv_bwd mix (lshr, and_or, ds128, 2 pk_fma)",
     "v_exp_f32"};
 // wave-instructions per inner-loop body of each mix (what the rate is counted in)
-static const int kMixInsts[MIX_COUNT] = {32, 32, 32, 32, 16, 40, 40, 32};
+static const int kMixInsts[MIX_COUNT] = {128, 128, 128, 128, 64, 160, 160, 128};
 
-struct Rec { unsigned long long cyc, t0, t1; };
+struct Rec { unsigned long long t0, t1, r0, r1, hw; };
 
 template <int MIX>
 __global__ __launch_bounds__(256) void issue_probe(Rec* rec, float* sink, int reps, int lds_floats) {
@@ -53,36 +59,37 @@ __global__ __launch_bounds__(256) void issue_probe(Rec* rec, float* sink, int re
     unsigned addr[4];
     for (int i = 0; i < 4; ++i) addr[i] = (((unsigned)lane * 7u + i * 5u) & 15u) * 16u;
     __builtin_amdgcn_s_barrier();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int r = 0; r < reps; ++r) {
         if (MIX == MIX_FMA) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < 16; ++k)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(y));
         } else if (MIX == MIX_PK_FMA) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < 16; ++k)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[i]) : "v"(px), "v"(py));
         } else if (MIX == MIX_PK_ADD) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < 16; ++k)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(px));
         } else if (MIX == MIX_AND_OR) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < 16; ++k)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(m), "v"(base));
         } else if (MIX == MIX_EXP) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < 16; ++k)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
         } else if (MIX == MIX_DS128) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < 16; ++k) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(row[i]) : "v"(addr[i]));
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -91,9 +98,9 @@ __global__ __launch_bounds__(256) void issue_probe(Rec* rec, float* sink, int re
             // conv_pool's inner body per tap pair and unit quad: one field extract of the packed codes,
             // the table address by and-or, one 16-byte row read, two packed adds into the four sums
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < 32; ++k) {
                 unsigned f, ad;
-                asm volatile("v_bfe_u32 %0, %1, %2, 8" : "=v"(f) : "v"(bits), "v"((unsigned)(k * 3)));
+                asm volatile("v_bfe_u32 %0, %1, %2, 8" : "=v"(f) : "v"(bits), "v"((unsigned)((k & 7) * 3)));
                 asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(ad) : "v"(f), "v"(m), "v"(base));
                 asm volatile("ds_read_b128 %0, %1" : "=v"(row[k & 3]) : "v"(ad));
                 if ((k & 3) == 3) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
@@ -105,9 +112,9 @@ __global__ __launch_bounds__(256) void issue_probe(Rec* rec, float* sink, int re
             // conv_bwd's body per (window, tap): a shift of the code word, the row address by and-or, one
             // one-hot row read (16 bytes), two packed FMAs of the pooled gradient into the tap's sums
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < 32; ++k) {
                 unsigned f, ad;
-                asm volatile("v_lshrrev_b32 %0, %1, %2" : "=v"(f) : "v"((unsigned)(2 * k)), "v"(bits));
+                asm volatile("v_lshrrev_b32 %0, %1, %2" : "=v"(f) : "v"((unsigned)(2 * (k & 7))), "v"(bits));
                 asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(ad) : "v"(f), "v"(m), "v"(base));
                 asm volatile("ds_read_b128 %0, %1" : "=v"(row[k & 3]) : "v"(ad));
                 if ((k & 3) == 3) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
@@ -118,12 +125,16 @@ __global__ __launch_bounds__(256) void issue_probe(Rec* rec, float* sink, int re
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
     float out = row[0][0] + row[1][1] + row[2][2] + row[3][3];
     for (int i = 0; i < 8; ++i) out += a[i] + p[i][0] + p[i][1] + (float)u[i];
     sink[(size_t)blockIdx.x * 256 + tid] = out;
     if (lane == 0) {
         Rec& r = rec[(size_t)blockIdx.x * 4 + (tid >> 6)];
-        r.cyc = t1 - t0; r.t0 = t0; r.t1 = t1;
+        r.t0 = t0; r.t1 = t1; r.r0 = r0; r.r1 = r1;
+        // HW_REG_HW_ID (4): wave[3:0] simd[5:4] pipe[7:6] cu[11:8] sh[12] se[15:13]; HW_REG_XCC_ID (20)
+        r.hw = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+               ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
     }
 }
 
@@ -145,22 +156,37 @@ static void run(int W, Rec* rec, float* sink, int reps) {
     }
     std::vector<Rec> h((size_t)grid * 4);
     CK(hipMemcpy(h.data(), rec, h.size() * sizeof(Rec), hipMemcpyDeviceToHost));
-    std::vector<double> cyc;
-    unsigned long long tmin = ~0ull, tmax = 0;
-    for (auto& r : h) { cyc.push_back((double)r.cyc); tmin = std::min(tmin, r.t0); tmax = std::max(tmax, r.t1); }
-    std::sort(cyc.begin(), cyc.end());
     const double insts = (double)reps * kMixInsts[MIX];
-    const double p50 = cyc[cyc.size() / 2], p90 = cyc[cyc.size() * 9 / 10];
-    // all W waves of a SIMD run the same stream at the same time: the SIMD issued W x insts in p50 cycles
-    printf("%-46s W=%d  wave cycles p50 %9.0f p90 %9.0f  -> %.3f wave-inst/clk/SIMD = %.2f clk per wave-inst  (event %.1f us, clock %.2f GHz)\n",
-           kMixName[MIX], W, p50, p90, W * insts / p50, p50 / (W * insts), ms * 1e3, p50 / (ms * 1e3) / 1e3);
+    struct Simd { int n = 0; unsigned long long a = ~0ull, b = 0; };
+    std::map<unsigned long long, Simd> simds;
+    std::vector<double> clk;
+    for (auto& r : h) {
+        const unsigned hw = (unsigned)r.hw, xcc = (unsigned)(r.hw >> 32) & 15;
+        const unsigned long long key = ((unsigned long long)xcc << 16) | (((hw >> 13) & 7) << 12) | (((hw >> 12) & 1) << 11) |
+                                       (((hw >> 8) & 15) << 4) | ((hw >> 4) & 3);
+        Simd& sd = simds[key];
+        sd.n++; sd.a = std::min(sd.a, r.t0); sd.b = std::max(sd.b, r.t1);
+        if (r.r1 > r.r0) clk.push_back((double)(r.t1 - r.t0) / (double)(r.r1 - r.r0) * 0.1);   // GHz
+    }
+    std::sort(clk.begin(), clk.end());
+    std::map<int, std::vector<double>> rate;          // waves on the SIMD -> wave-inst per clk
+    for (auto& kv : simds) rate[kv.second.n].push_back(kv.second.n * insts / (double)(kv.second.b - kv.second.a));
+    printf("%-46s cap W=%d  event %7.1f us  clock %.2f GHz  %zu SIMDs |", kMixName[MIX], W, ms * 1e3,
+           clk.empty() ? 0.0 : clk[clk.size() / 2], simds.size());
+    for (auto& kv : rate) {
+        auto& v = kv.second; std::sort(v.begin(), v.end());
+        if (v.size() * 20 < simds.size()) continue;                  // (fewer than 5 % of the SIMDs: noise)
+        printf("  %d waves/SIMD (%zu SIMDs): %.3f inst/clk = %.2f clk/inst", kv.first, v.size(), v[v.size() / 2], 1.0 / v[v.size() / 2]);
+    }
+    printf("\n");
 }
 
 int main() {
     Rec* rec; float* sink;
     CK(hipMalloc(&rec, (size_t)256 * 8 * 4 * sizeof(Rec)));
+    CK(hipMemset(rec, 0, (size_t)256 * 8 * 4 * sizeof(Rec)));
     CK(hipMalloc(&sink, (size_t)256 * 8 * 256 * sizeof(float)));
-    const int reps = 2000;
+    const int reps = 500;
     const int Ws[] = {1, 2, 4, 5, 8};
     for (int W : Ws) {
         run<MIX_FMA>(W, rec, sink, reps);
