@@ -387,12 +387,13 @@ struct fin_args {
     const float* S12p; const double* m; const double* Gw; const double* mug; const double* sig1;
     const float* g1; float* g_conv_w; float* g_conv_b; float* g_bn1_w; float* g_bn1_b;
     int K4; int freeze_n; int NG;
+    int dsp_stride, dsp_count;        // Dspp[u][dsp_stride][4k]: the first dsp_count partials are live
 };
 
 __device__ __forceinline__ void fin_unit(const fin_args& f, const float* __restrict__ Dspp, int u,
                                          int tid, int nthr, int Bs, int B) {
     const int K4 = f.K4;
-    const int NT = Bs / 64, nt = ((B + 63) / 64 + CB_TILES - 1) / CB_TILES;   // conv_bwd partials
+    const int NT = f.dsp_stride, nt = f.dsp_count;     // the filter-gradient partials of this step
     const int NT16 = Bs / 16, nt16 = (B + 15) / 16;
     // S1, S2: the per-tile partials are spread over the threads (one load each, then a fixed-order
     // tree) instead of every thread walking all of them in batches
@@ -585,7 +586,7 @@ __global__ __launch_bounds__(64, 3) void conv_bwd_kernel(const float* __restrict
     // sums over the 64 lanes through LDS, one base at a time: every lane parks K values as a column
     // of a [K][65] tile (the code tiles are dead by now), then lane j adds up row j
     float* red = reinterpret_cast<float*>(smem) + 16;
-    float* out = Dspp + ((size_t)u * (Bs / 64) + blockIdx.x) * 4 * K;
+    float* out = Dspp + ((size_t)u * (Bs / 32) + blockIdx.x) * 4 * K;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         __syncthreads();
@@ -623,7 +624,216 @@ __global__ __launch_bounds__(64, 3) void conv_bwd_kernel(const float* __restrict
                  return EXPLAINN_E_UNSUPPORTED;                                                \
     }
 
+// ---------------------------------------------------------------------------------------------
+// Filter gradient on the bf16 matrix core (round 3).  The pooled gradient of (unit u, window w,
+// sequence b) lands on ONE position p = 7w + idx[u][w][b]; with D[u][(b,p)] = dy there and 0
+// elsewhere, and the window indicator F[(b,p)][(a,j)] = [s[b][p+j] == a],
+//     dW[u][a][j] = sum_(b,p) D[u][(b,p)] F[(b,p)][(a,j)]
+// is a GEMM (M = units, N = 4k filter taps, K = sequences x positions) whose B operand is a BIT matrix
+// and whose A operand is 1/7 dense.  F is exact in bf16; dy is split exactly into three bf16 pieces
+// (hi / mid / lo, 8+8+8 mantissa bits, as passA does): every product is exact and the matrix core
+// accumulates in fp32, so this is an fp32 sum of the same terms the register formulation adds, in
+// another order.  (The register formulation -- one LDS row fetch and two packed FMAs per (window,
+// tap, 64 sequences) -- is LDS-bandwidth and issue bound at 42 us for C2: tools/issue_rate.hip
+// measures 3.8 clk per wave-instruction for its mix.  Here the same sum costs 1.66 M MFMAs = 11 us
+// of matrix-core time.)  N bases need no correction: an N sets no bit in any base's mask.
+//
+// k-step of v_mfma_f32_16x16x32_bf16 = (one position p, 32 sequences).  Workgroup = (block of 32
+// sequences, tile of 16 units); its four waves take the windows of a chunk in turn.
+//   B operand  the batch as bit masks per (base, position) already exists (pack.hip: bm, the input
+//              of the moment kernel).  The workgroup expands the 32 bits of its sequence block to
+//              bf16 once per (base, position): X[q][a][g] = the 8 bf16 of sequences 8g..8g+7 -- the
+//              B fragment of column (a, j) at position p is the 16 bytes X[p + j][a][g]: one
+//              ds_read_b128 per (16-column tile, position), no arithmetic.
+//   A operand  lane (unit row c, g) loads dy and idx of its 8 sequences for window w once (32 + 8
+//              contiguous bytes), splits dy into the three pieces, and for each of the 7 positions of
+//              the window keeps the pieces where idx == r (packed 16-bit compare -> mask).
+// 15 MFMAs (5 column tiles x 3 pieces) per (unit tile, window, position, 32 sequences).
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 cb_bf16x8;
+typedef uint32_t cb_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short cb_u16x2 __attribute__((ext_vector_type(2)));
+#define CBM_CHUNK 32                  // pooling windows per LDS image of the expanded masks
+__host__ __device__ constexpr int cbm_tiles(int K) { return (4 * K + 15) / 16; }
+
+template <int K>
+__global__ __launch_bounds__(256, 3) void conv_bwd_mm_kernel(
+    const float* __restrict__ dy, const uint8_t* __restrict__ idx,
+    const unsigned long long* __restrict__ bm, float* __restrict__ Dspp, int U, int n, int Bs, int B,
+    int NT64, int Lp, int LQ, int NP) {
+    constexpr int K4 = 4 * K, NTL = cbm_tiles(K);
+    extern __shared__ __attribute__((aligned(16))) unsigned char cbsm[];
+    cb_u32x4* X = reinterpret_cast<cb_u32x4*>(cbsm);           // [LQ positions][4 bases][4 slots] x 16 bytes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+    const int b0 = blockIdx.x * 32, u0 = blockIdx.y * 16;
+    const int tile64 = b0 >> 6, half = (b0 >> 5) & 1;
+    const int ua = min(u0 + c, U - 1);                          // the unit this lane feeds as an A row
+    // sequences past the batch: their idx bytes are forced to 7, which no position matches
+    uint32_t dead0 = 0u, dead1 = 0u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (b0 + 8 * g + j >= B) { if (j < 4) dead0 |= 7u << (8 * j); else dead1 |= 7u << (8 * (j - 4)); }
+    // Column order inside the matrix-core tiles: n = 4 j + a (tap-major), so the 16 columns of tile t
+    // are taps 4t .. 4t+3 x the four bases.  X holds one 256-byte row per position q, [base][slot]
+    // with slot = g ^ 2 (q & 1): with that swizzle the 16 lanes of every ds_read_b128 lane group hit
+    // 16 distinct 16-byte bank slots whatever q is (searched exhaustively; the plain [a][q][g]
+    // image was 2.6-way conflicted).  Byte offset of this lane's fragment for column tile t at an
+    // EVEN relative position; an odd one flips bit 5 (slot ^ 2).
+    const int ca = c & 3;
+    uint32_t boff[NTL];
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+        const int j = min(4 * t + (c >> 2), K - 1);
+        boff[t] = (uint32_t)(j * 256 + ca * 64 + ((g ^ ((j & 1) << 1)) * 16));
+    }
+    f32x4b acc[NTL];
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) acc[t] = f32x4b{0.f, 0.f, 0.f, 0.f};
+    const float* __restrict__ dyu = dy + (size_t)ua * n * Bs + b0 + 8 * g;
+    const uint8_t* __restrict__ ixu = idx + (size_t)ua * n * Bs + b0 + 8 * g;
+    STAMP(0);
+    for (int wc = 0; wc < n; wc += CBM_CHUNK) {
+        const int nwin = min(CBM_CHUNK, n - wc), q0 = POOLW * wc, nq = POOLW * nwin + K - 1;
+        // this wave's first window of the chunk: its loads fly while the masks are expanded
+        int w = wc + wave;
+        float4 d0 = make_float4(0.f, 0.f, 0.f, 0.f), d1 = d0;
+        uint2 iw = make_uint2(0u, 0u);
+        if (w < wc + nwin) {
+            d0 = *reinterpret_cast<const float4*>(dyu + (size_t)w * Bs);
+            d1 = *reinterpret_cast<const float4*>(dyu + (size_t)w * Bs + 4);
+            iw = *reinterpret_cast<const uint2*>(ixu + (size_t)w * Bs);
+        }
+        __syncthreads();                                        // the previous chunk's X is dead
+        for (int e = tid; e < 4 * nq; e += 256) {
+            const int a = e / nq, q = e - a * nq;
+            const unsigned long long m = bm[((size_t)a * NT64 + tile64) * Lp + q0 + q];
+            const uint32_t bits32 = half ? (uint32_t)(m >> 32) : (uint32_t)m;
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                const uint32_t by = (bits32 >> (8 * gg)) & 0xffu;
+                cb_u32x4 v;
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+                    v[d] = ((by >> (2 * d)) & 1u) * 0x00003f80u + ((by >> (2 * d + 1)) & 1u) * 0x3f800000u;
+                X[(q * 4 + a) * 4 + (gg ^ ((q & 1) << 1))] = v;
+            }
+        }
+        __syncthreads();
+        if (wc == 0) STAMP(1);
+        for (; w < wc + nwin; w += 4) {
+            // pieces of the 8 gradients: x = hi + mid + lo exactly, each piece a bf16
+            const float xs[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+            uint32_t ph[4], pm[4], pl[4];
+            {
+                uint32_t hb[8], mb[8], lb[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t xb = __float_as_uint(xs[j]);
+                    const float r1 = xs[j] - __uint_as_float(xb & 0xffff0000u);
+                    const uint32_t r1b = __float_as_uint(r1);
+                    const float r2 = r1 - __uint_as_float(r1b & 0xffff0000u);
+                    hb[j] = xb; mb[j] = r1b; lb[j] = __float_as_uint(r2);
+                }
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {       // (upper halves of sequences 2d+1, 2d) -> one dword
+                    ph[d] = __builtin_amdgcn_perm(hb[2 * d + 1], hb[2 * d], 0x07060302u);
+                    pm[d] = __builtin_amdgcn_perm(mb[2 * d + 1], mb[2 * d], 0x07060302u);
+                    pl[d] = __builtin_amdgcn_perm(lb[2 * d + 1], lb[2 * d], 0x07060302u);
+                }
+            }
+            // one-hot of the argmax offset per sequence, as 16-bit pairs in the order of the packed
+            // pieces: bit r of a half says "this sequence's gradient sits at position 7w + r"
+            const uint32_t i0 = iw.x | dead0, i1 = iw.y | dead1;
+            uint32_t ip[4];
+            ip[0] = (1u << (i0 & 0xffu)) | (0x10000u << ((i0 >> 8) & 0xffu));
+            ip[1] = (1u << ((i0 >> 16) & 0xffu)) | (0x10000u << (i0 >> 24));
+            ip[2] = (1u << (i1 & 0xffu)) | (0x10000u << ((i1 >> 8) & 0xffu));
+            ip[3] = (1u << ((i1 >> 16) & 0xffu)) | (0x10000u << (i1 >> 24));
+            const int wn = w + 4;                               // next window of this wave: in flight below
+            if (wn < wc + nwin) {
+                d0 = *reinterpret_cast<const float4*>(dyu + (size_t)wn * Bs);
+                d1 = *reinterpret_cast<const float4*>(dyu + (size_t)wn * Bs + 4);
+                iw = *reinterpret_cast<const uint2*>(ixu + (size_t)wn * Bs);
+            }
+            const uint32_t wbase = (uint32_t)(POOLW * (w - wc) * 256);
+            const uint32_t wpar = (uint32_t)((w - wc) & 1) << 5;   // parity of this window's first position
+            typedef __attribute__((address_space(3))) cb_u32x4 lds_u32x4;
+            typedef __attribute__((address_space(3))) unsigned char lds_uchar;
+            const uint32_t xbase = (uint32_t)(size_t)(const lds_uchar*)cbsm + wbase;
+#pragma unroll
+            for (int r = 0; r < POOLW; ++r) {
+                cb_u32x4 ah, am, al;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    // 0xffff per half whose bit r is set
+                    const uint32_t mk = __umul24((ip[d] >> r) & 0x00010001u, 0xffffu);
+                    ah[d] = ph[d] & mk; am[d] = pm[d] & mk; al[d] = pl[d] & mk;
+                }
+                const cb_bf16x8 fh = __builtin_bit_cast(cb_bf16x8, ah), fm = __builtin_bit_cast(cb_bf16x8, am),
+                                fl = __builtin_bit_cast(cb_bf16x8, al);
+                cb_bf16x8 fb[NTL];
+#pragma unroll
+                for (int t = 0; t < NTL; ++t)
+                    fb[t] = __builtin_bit_cast(cb_bf16x8, *(const lds_u32x4*)(size_t)(
+                        xbase + ((boff[t] ^ wpar ^ (uint32_t)((r & 1) << 5)) + (uint32_t)(r * 256))));
+                // piece outermost: consecutive MFMAs go to different accumulators
+#pragma unroll
+                for (int t = 0; t < NTL; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh, fb[t], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NTL; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fm, fb[t], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NTL; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl, fb[t], acc[t], 0, 0, 0);
+            }
+        }
+    }
+    STAMP(2);
+    // the four waves' tiles are added in a fixed order through LDS (the mask image is dead), then
+    // stored as ONE partial per (sequence block, unit): D[row = unit 4g + i][col c] of column tile t
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(cbsm);                // [4 waves][NTL][4][64]
+#pragma unroll
+    for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[((wave * NTL + t) * 4 + i) * 64 + lane] = acc[t][i];
+    __syncthreads();
+    for (int e = tid; e < NTL * 4 * 64; e += 256) {
+        const float v = ((red[e] + red[NTL * 256 + e]) + red[2 * NTL * 256 + e]) + red[3 * NTL * 256 + e];
+        const int l = e & 63, i = (e >> 6) & 3, t = e >> 8;
+        const int u = u0 + 4 * (l >> 4) + i, j = 4 * t + ((l & 15) >> 2), a = l & 3;
+        if (u < U && j < K) Dspp[((size_t)u * NP + blockIdx.x) * K4 + a * K + j] = v;
+    }
+    STAMP(3);
+}
+
+static size_t conv_bwd_mm_lds(const explainn_ctx* c, int* lq_out) {
+    const int nwin = c->n < CBM_CHUNK ? c->n : CBM_CHUNK;
+    const int LQ = POOLW * nwin + c->k - 1;
+    if (lq_out) *lq_out = LQ;
+    size_t sm = (size_t)4 * LQ * 64;
+    const size_t red = (size_t)4 * cbm_tiles(c->k) * 256 * sizeof(float);
+    return sm > red ? sm : red;
+}
+
+int launch_conv_bwd_mm(explainn_ctx* c, int B, hipStream_t s) {
+    int LQ = 0;
+    const size_t sm = conv_bwd_mm_lds(c, &LQ);
+    const int NP = (B + 31) / 32;
+    const dim3 grid(NP, (c->U + 15) / 16);
+#define CALL(KK)                                                                                   \
+    hipLaunchKernelGGL(conv_bwd_mm_kernel<KK>, grid, dim3(256), sm, s, c->dy, c->idx, c->bm, c->Dspp, \
+                       c->U, c->n, c->Bs, B, (B + 63) / 64, c->Lp, LQ, c->Bs / 32)
+    KB_DISPATCH(c->k, CALL);
+#undef CALL
+    LAUNCH_CHECK();
+    c->dsp_stride = c->Bs / 32; c->dsp_count = NP;
+    return EXPLAINN_OK;
+}
+
 int launch_conv_bwd(explainn_ctx* c, int B, hipStream_t s) {
+    {   // A/B switch while both formulations exist (EXPLAINN_CONV_BWD=reg selects the register form)
+        const char* e = getenv("EXPLAINN_CONV_BWD");
+        if (!(e && e[0] == 'r')) return launch_conv_bwd_mm(c, B, s);
+    }
     const dim3 grid(((B + 63) / 64 + CB_TILES - 1) / CB_TILES, c->U);
     // chunk tiles (see the kernel: [PWC + NWC][64] words) or the [k][65] reduction tile
     const int pwc = ((POOLW * 32 + c->k + 15) >> 4) + 2, nwc = ((POOLW * 32 + c->k + 31) >> 5) + 2;
@@ -639,6 +849,7 @@ int launch_conv_bwd(explainn_ctx* c, int B, hipStream_t s) {
     KB_DISPATCH(c->k, CALL);
 #undef CALL
     LAUNCH_CHECK();
+    c->dsp_stride = c->Bs / 32; c->dsp_count = (int)grid.x;
     return EXPLAINN_OK;
 }
 
@@ -653,13 +864,23 @@ __global__ __launch_bounds__(128) void fin_bwd_kernel(const fin_args fin,
 int launch_fin_bwd(explainn_ctx* c, const explainn_params* p, const explainn_grads* g, int B,
                    int freeze_n, hipStream_t s) {
     const fin_args fin = {c->S12p, c->m, c->Gw, c->mug, c->sig1, p->bn1_w, g->conv_w, g->conv_b,
-                          g->bn1_w, g->bn1_b, c->K4, freeze_n, fc_ng(c->NQ)};
+                          g->bn1_w, g->bn1_b, c->K4, freeze_n, fc_ng(c->NQ), c->dsp_stride, c->dsp_count};
     hipLaunchKernelGGL(fin_bwd_kernel, dim3(c->U), dim3(128), 0, s, fin, c->Dspp, c->Bs, B);
     LAUNCH_CHECK();
     return EXPLAINN_OK;
 }
 
 int bwd_configure(explainn_ctx* c) {
+    {
+        const size_t sm = conv_bwd_mm_lds(c, nullptr);
+        if (sm > 48 * 1024) {
+#define CALL(KK)                                                                                  \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bwd_mm_kernel<KK>),   \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm))
+            KB_DISPATCH(c->k, CALL);
+#undef CALL
+        }
+    }
     if (c->n > 72)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mid_big_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -83,7 +83,8 @@ struct explainn_ctx {
     float* k0p;           // [U][NS]
     float* dy;            // [U4][n][Bs]
     float* S12p;          // [U][NG][Bs/16][2] per (w-tile group, 16-sequence tile): sum dy, sum dy*chat
-    float* Dspp;          // [U][Bs/64][4k]
+    float* Dspp;          // [U][Bs/32][4k]     filter-gradient partials (one per 32-sequence block)
+    int dsp_stride, dsp_count;   // partial slots per unit / how many of them the last conv_bwd wrote
     float* dlogits;       // [maxB][T]         (train_step only)
     float* dlT;           // [T][Bs]   d loss / d logits, task-major (head GEMMs, T > HEAD_GEMM_MIN_T)
     double* lossp;        // [64]      per-block partial sums of the loss

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(128) void dense_conv_bwd_kernel(const float* __rest
             }
         }
     }
-    if (mine) Dspp[((size_t)u * (Bs / 64) + blockIdx.x) * K4 + tid] = acc;
+    if (mine) Dspp[((size_t)u * (Bs / 32) + blockIdx.x) * K4 + tid] = acc;
 }
 
 __global__ __launch_bounds__(256) void dense_conv_act_kernel(const float* __restrict__ x,
@@ -223,6 +223,7 @@ int launch_dense_conv_bwd(explainn_ctx* c, const float* x, int B, hipStream_t s)
     hipLaunchKernelGGL(dense_conv_bwd_kernel, dim3((B + DENSE_BWD_SEQS - 1) / DENSE_BWD_SEQS, c->U),
                        dim3(128), 0, s, x, c->dy, c->idx, c->Dspp, c->k, c->L, c->n, c->Bs, B);
     LAUNCH_CHECK();
+    c->dsp_stride = c->Bs / 32; c->dsp_count = (B + DENSE_BWD_SEQS - 1) / DENSE_BWD_SEQS;
     return EXPLAINN_OK;
 }
 
