@@ -263,6 +263,29 @@ __device__ __forceinline__ void filter_tables_unit(const float* __restrict__ con
     }
 }
 
+// (unit, chunk) of a workgroup of a per-unit kernel launched on a grid (chunks, units rounded up to 8
+// [, groups]).  Workgroups are dealt to the 8 XCDs round-robin in dispatch order (x fastest), so
+// blockIdx-order (chunk, unit) puts the G chunks of one unit on G different XCDs and every one of
+// them pulls the unit's weight fragments through its own L2.  This mapping gives the workgroups
+// with equal (linear id mod 8) -- one XCD -- the chunks of the same unit: the fragments cross the
+// fabric once and the other chunks hit that L2.  Placement is a speed matter only (the hardware
+// promises nothing): results do not depend on it.  Returns false for the padding units.
+#ifndef EXPLAINN_XCD_MAP
+#define EXPLAINN_XCD_MAP 1
+#endif
+__device__ __forceinline__ bool unit_chunk_of_block(int U, int& u, int& chunk) {
+#if EXPLAINN_XCD_MAP
+    const int G = gridDim.x, L = blockIdx.y * G + blockIdx.x;
+    const int slot = L >> 3;
+    u = (slot / G) * 8 + (L & 7);
+    chunk = slot - (slot / G) * G;
+#else
+    u = blockIdx.y; chunk = blockIdx.x;
+#endif
+    return u < U;
+}
+__host__ inline int units_grid(int U) { return (U + 7) & ~7; }
+
 // q = exp(alpha*ext + shift): every consumer must evaluate it identically
 __device__ __forceinline__ float qval(float alpha, float ext, float shift) {
     // v_exp_f32 path: ~2 ulp, far inside the 1e-4 parity budget, and 10x fewer instructions

@@ -113,7 +113,9 @@ __global__ __launch_bounds__(64 * fc_fwd_waves(NQ)) void fc_fwd_kernel(
     float4* Af = reinterpret_cast<float4*>(fsm);            // [FC_MT][NK4Q][64] float4 (4 k-steps each)
     float* sh2s = fsm + FC_MT * NK4Q * 64 * 4;               // [112]
     float* v2s = sh2s + FC_MT * 16;                          // [112]
-    const int u = blockIdx.y, bx = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int u, bx;
+    if (!unit_chunk_of_block(U, u, bx)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
     const float* __restrict__ eu = ext + (size_t)u * n * Bs;
     const int bt0 = (bx * FW + wave) * FC_BTW;
@@ -252,7 +254,9 @@ __global__ __launch_bounds__(64 * fc_fwd_waves(NQ), fc_ks32(NQ) == 1 ? 5 : 2) vo
     u32x4* Ah = reinterpret_cast<u32x4*>(fsm);               // [FC_MT][KS][3][64] x 8 bf16
     float* sh2s = fsm + FC_MT * KS * 3 * 256;                // [112]
     float* v2s = sh2s + FC_MT * 16;                          // [112]
-    const int u = blockIdx.y, bx = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int u, bx;
+    if (!unit_chunk_of_block(U, u, bx)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
     const float* __restrict__ eu = ext + (size_t)u * n * Bs;
     const int bt0 = (bx * FW + wave) * FC_BTW;
@@ -432,7 +436,7 @@ static int fc_fwd_configure_nm() {
 int launch_fc_fwd(explainn_ctx* c, const explainn_params* p, int B, bool train,
                   const uint8_t* keep_mask, float drop_p, uint64_t seed, hipStream_t s) {
     const int tiles = (B + 15) / 16;
-    const dim3 grid(fc_fwd_blocks(B, c->NQ), c->U);
+    const dim3 grid(fc_fwd_blocks(B, c->NQ), units_grid(c->U));
     int mode = train ? 1 : 0;
     float scale = 1.f;
     uint32_t thresh = 0;
@@ -625,6 +629,7 @@ __global__ __launch_bounds__(64 * PA_WAVES, pa_wgt(NQ) <= 2 ? 3 : 2) void passA_
     constexpr int XT_HALFS = 3 * ROWS * PA_LD, REGION = XT_HALFS * 2 + 2 * 64 * 4 * 4;
     static_assert(REGION >= FC_MT * WGT * 64 * 16, "accumulator tile must fit the wave's LDS region");
     __shared__ __attribute__((aligned(16))) unsigned char pal[PA_WAVES][REGION];
+    // (plain blockIdx mapping: this kernel stages no per-unit tables, and it sits at its register cap)
     const int u = blockIdx.y, ch = blockIdx.x, grp = blockIdx.z, lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: LDS bases stay scalar
     uint16_t* xt = reinterpret_cast<uint16_t*>(pal[wave]);
@@ -815,14 +820,16 @@ __global__ __launch_bounds__(256) void passB_kernel(
     const float* __restrict__ shift, const float* __restrict__ dz, const uint4* __restrict__ bits,
     const float* __restrict__ Ttf, const float* __restrict__ Mff, const float* __restrict__ k0p,
     const double* __restrict__ mug, const double* __restrict__ sig1, float* __restrict__ dy,
-    float* __restrict__ S12p, int n, int Bs, int B) {
+    float* __restrict__ S12p, int n, int Bs, int B, int U) {
     constexpr int NS = ns_stride(NQ), NW16 = fc_nw16(NQ), WGT = fc_wgt(NQ), NG = fc_ng(NQ);
     constexpr int TBW = 3 * 4 * 256, MK = 4 * NW16;    // floats of one w tile's T pieces; k-steps of M.q
     extern __shared__ __attribute__((aligned(16))) float smemB[];
     float* Tf = smemB;                                 // [WGT][3 pieces][4 k-steps][64 lanes][8 bf16]
     float* Mf = Tf + WGT * TBW;                        // [WGT][MK][64]
     float* k0s = Mf + WGT * MK * 64;                   // [WGT*16]
-    const int u = blockIdx.y, bx = blockIdx.x, grp = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int u, bx;
+    if (!unit_chunk_of_block(U, u, bx)) return;
+    const int grp = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int j0 = grp * WGT;                          // first w tile of this group
     const int ntile = min(WGT, NW16 - j0);             // w tiles this group really has
@@ -964,9 +971,9 @@ int launch_passB(explainn_ctx* c, int B, hipStream_t s) {
     const int tiles = (B + 15) / 16;
     const int nx = (tiles + 4 * PB_BTW - 1) / (4 * PB_BTW);
 #define CALL(N)                                                                                  \
-    hipLaunchKernelGGL(passB_kernel<N>, dim3(nx, c->U, fc_ng(N)), dim3(256), passB_lds<N>(), s,  \
+    hipLaunchKernelGGL(passB_kernel<N>, dim3(nx, units_grid(c->U), fc_ng(N)), dim3(256), passB_lds<N>(), s,  \
                        c->ext, c->alpha, c->shift, c->dz, c->bits, c->Ttf, c->Mff, c->k0p, c->mug,  \
-                       c->sig1, c->dy, c->S12p, c->n, c->Bs, B)
+                       c->sig1, c->dy, c->S12p, c->n, c->Bs, B, c->U)
     NQ_DISPATCH(c->NQ, CALL);
 #undef CALL
     LAUNCH_CHECK();
