@@ -76,7 +76,7 @@ void carve(explainn_ctx* c, Carver& cv) {
     cv.take(&c->k0p, U * NS);
     cv.take(&c->dy, U4 * n * Bs);
     cv.take(&c->S12p, U * fc_ng(c->NQ) * (Bs / 16) * 2);
-    cv.take(&c->Dspp, U * (Bs / 32) * K4);
+    cv.take(&c->Dspp, U * (Bs / 4) * K4);
     cv.take(&c->dlogits, (int64_t)c->maxB * c->T);
     cv.take(&c->flags, 64);
     cv.take(&c->dlT, (int64_t)c->T * Bs);

@@ -15,7 +15,6 @@
 typedef float f32x16b __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4b __attribute__((ext_vector_type(4)));
-#define CB_PF 4              // pooling windows whose dy / idx a conv_bwd lane fetches per batch
 
 // Register budget: this kernel must stay at <= 64 VGPRs so that TWO 1024-thread blocks share a CU --
 // 300 units on 256 CUs otherwise take two rounds.  (Batching the per-channel partial-sum loads below
@@ -383,6 +382,8 @@ int launch_mid_bwd(explainn_ctx* c, const explainn_params* p, const explainn_gra
 // ---------------------------------------------------------------------------------------------
 // BatchNorm1 backward closed form for one unit, by `nthr` threads of
 // one block: sums the per-tile partials in fixed order -> dW, d gamma1, d beta1.
+#define FIN_THREADS 320              // fin_bwd block: 4 groups of 76 taps at k = 19
+#define FIN_MAXGRP 8
 struct fin_args {
     const float* S12p; const double* m; const double* Gw; const double* mug; const double* sig1;
     const float* g1; float* g_conv_w; float* g_conv_b; float* g_bn1_w; float* g_bn1_b;
@@ -397,7 +398,7 @@ __device__ __forceinline__ void fin_unit(const fin_args& f, const float* __restr
     const int NT16 = Bs / 16, nt16 = (B + 15) / 16;
     // S1, S2: the per-tile partials are spread over the threads (one load each, then a fixed-order
     // tree) instead of every thread walking all of them in batches
-    __shared__ double fin_red[2][4];
+    __shared__ double fin_red[2][16];
     double S1 = 0, S2 = 0;
     for (int t = tid; t < f.NG * nt16; t += nthr) {      // (w-tile group, 16-sequence tile) partials
         const int grp = t / nt16, tl = t - grp * nt16;
@@ -410,201 +411,38 @@ __device__ __forceinline__ void fin_unit(const fin_args& f, const float* __restr
     S1 = 0; S2 = 0;
     for (int w = 0; w < (nthr + 63) / 64; ++w) { S1 += fin_red[0][w]; S2 += fin_red[1][w]; }
     const double sg = f.sig1[u], a = (double)f.g1[u] / sg, mu = f.mug[u];
-    for (int i = tid; i < K4; i += nthr) {
+    // The filter-gradient partials: nt of them per tap (64 at C2).  The block's threads form
+    // NGRP = nthr / K4 groups of K4; group q takes partials q, q + NGRP, ... with up to sixteen loads
+    // in flight per thread (one memory round trip for 64 partials instead of four), sums them in
+    // fp64 in a fixed order, and the groups are combined through LDS in group order.
+    __shared__ double fin_part[FIN_MAXGRP][4 * MAX_K];
+    const int ngrp = min(FIN_MAXGRP, max(1, nthr / K4));
+    const int grp = tid / K4, i = tid - grp * K4;
+    if (grp < ngrp) {
         double D = 0;
-        for (int t0 = 0; t0 < nt; t0 += 16) {          // sixteen partials in flight, fixed-order sum
+        for (int t0 = grp; t0 < nt; t0 += 16 * ngrp) {     // sixteen partials in flight, fixed-order sum
             float pv[16];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) pv[q] = Dspp[((size_t)u * NT + min(t0 + q, nt - 1)) * K4 + i];
+            for (int q = 0; q < 16; ++q) pv[q] = Dspp[((size_t)u * NT + min(t0 + q * ngrp, nt - 1)) * K4 + i];
 #pragma unroll
             for (int q = 0; q < 16; ++q) KEEP(pv[q]);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) D += (t0 + q < nt) ? (double)pv[q] : 0.0;
+            for (int q = 0; q < 16; ++q) D += (t0 + q * ngrp < nt) ? (double)pv[q] : 0.0;
         }
-        const double val = a * (D - S1 * f.m[i] - (S2 / sg) * (f.Gw[(size_t)u * K4 + i] - mu * f.m[i]));
-        f.g_conv_w[(size_t)u * K4 + i] = (u < f.freeze_n) ? 0.f : (float)val;
+        fin_part[grp][i] = D;
+    }
+    __syncthreads();
+    if (tid < K4) {
+        double D = 0;
+        for (int q = 0; q < ngrp; ++q) D += fin_part[q][tid];
+        const double val = a * (D - S1 * f.m[tid] - (S2 / sg) * (f.Gw[(size_t)u * K4 + tid] - mu * f.m[tid]));
+        f.g_conv_w[(size_t)u * K4 + tid] = (u < f.freeze_n) ? 0.f : (float)val;
     }
     if (tid == 0) {
         f.g_bn1_b[u] = (float)S1;
         f.g_bn1_w[u] = (float)S2;
         f.g_conv_b[u] = 0.f;
     }
-}
-
-template <int K>
-__global__ __launch_bounds__(64, 3) void conv_bwd_kernel(const float* __restrict__ dy,
-                                                         const uint8_t* __restrict__ idx,
-                                                         const uint32_t* __restrict__ pk2,
-                                                         const uint32_t* __restrict__ nmask,
-                                                         float* __restrict__ Dspp, int U, int n,
-                                                         int Bs, int PW, int NW, int nlds_off,
-                                                         int B) {
-    // One wavefront = CB_TILES x 64 sequences x one unit; lane = sequence.  The partial sums of a lane
-    // live in REGISTERS: per tap the sums for bases C,G,T; base A is recovered at the end as
-    // (sum of all dy) - C - G - T.  N positions are packed as 'C'; the lanes that have one also add
-    // that dy to a per-tap LDS cell, which is taken out of C at the end.  (LDS float atomics
-    // serialise per lane on gfx950 and LDS read-modify-write chains were latency-bound,
-    // profiles/r01_c.)  Two sequence tiles per wave: 2400 waves at C2, all resident at 3 waves per SIMD,
-    // which leaves the registers for the row prefetch below.
-    // The packed codes are staged per chunk of CBW pooling windows (the positions a chunk touches
-    // span CBW*7 + K - 1 bases): a fixed ~7 KB of LDS per wave whatever the sequence length, so the
-    // 5 waves/SIMD hold for L = 1000 too (staging the whole sequence cost 26 KB there and left
-    // 1.5 waves/SIMD).  Columns are lane-private: no barrier between chunks.
-    constexpr int CBW = 32;
-    constexpr int PWC = ((POOLW * CBW + K + 15) >> 4) + 2, NWC = ((POOLW * CBW + K + 31) >> 5) + 2;
-    extern __shared__ uint32_t smem[];        // one-hot rows [4] float4, pk2 chunk [PWC][64], nmask chunk [NWC][64]
-    uint32_t* pks = smem + 16;
-    uint32_t* nms = pks + (size_t)PWC * 64;
-    const int lane = threadIdx.x, u = blockIdx.y;
-    STAMP(0);
-    constexpr uint32_t KMASK = (K >= 32) ? 0xffffffffu : ((1u << K) - 1u);
-    // One-hot rows {c==A, c==C, c==G, c==T} per 2-bit code as floats: acc[j] += dy * row[code_j] is
-    // one ds_read_b128 (4 distinct addresses per wave: broadcast, no conflicts), one v_pk_fma_f32
-    // (C, G) and one v_fma_f32 (T) per tap; A = total - C - G - T at the end.  (Three compare-select-add triples per tap were 10 VALU instructions
-    // per tap and made this kernel the VALU-issue-bound maximum of the step, profiles/r01_final.)
-    f32x2 a12[K];
-    float a3[K];
-    float tot = 0.f;
-#pragma unroll
-    for (int j = 0; j < K; ++j) { a12[j] = f32x2{0.f, 0.f}; a3[j] = 0.f; }
-    // dy that landed in the C bucket because an N base is packed as 'C', per tap: one LDS float per
-    // tap, fed by the few lanes that have an N (one wavefront per block, so the order of the adds
-    // -- lane order, instruction order -- is fixed and the sum reproducible)
-    float* nlds = reinterpret_cast<float*>(smem) + nlds_off;
-    // the one-hot rows sit at the very start of the dynamic LDS, so that a row's address is the
-    // code field itself (no base add): row c = {c==C, c==G, c==T, 0}
-    float4* oh = reinterpret_cast<float4*>(smem);
-    if (lane < K) nlds[lane] = 0.f;
-    if (lane < 4) oh[lane] = make_float4(lane == 1 ? 1.f : 0.f, lane == 2 ? 1.f : 0.f, lane == 3 ? 1.f : 0.f, 0.f);
-    __syncthreads();
-    typedef __attribute__((address_space(3))) f32x4b lds_f32x4;
-    typedef __attribute__((address_space(3))) char lds_char;
-    // 32-bit LDS address of the rows (64-byte aligned: the code field is OR-ed in, one v_and_or_b32)
-    const uint32_t ohbase = (uint32_t)(size_t)(const lds_char*)(reinterpret_cast<const char*>(oh));
-    const float* __restrict__ dyu = dy + (size_t)u * n * Bs;
-    const uint8_t* __restrict__ idxu = idx + (size_t)u * n * Bs;
-    for (int tl = 0; tl < CB_TILES; ++tl) {
-    const int tile = blockIdx.x * CB_TILES + tl;
-    if (tile * 64 >= B) break;                         // wave-uniform
-    const int b = tile * 64 + lane;
-    for (int wc = 0; wc < n; wc += CBW) {
-        // chunk origin in words: POOLW*CBW = 224 positions = 14 code words = 7 mask words
-        const int w_lo = (POOLW * wc) >> 4, n_lo = (POOLW * wc) >> 5;
-        stage_columns2<PWC, NWC>(pks + lane, pk2 + (size_t)w_lo * Bs + b, min(PWC, PW - w_lo),
-                                 nms + lane, nmask + (size_t)n_lo * Bs + b, min(NWC, NW - n_lo), Bs);
-        if (wc == 0) STAMP(1);
-        const int wend = min(wc + CBW, n);
-        // dy / idx are fetched CB_PF windows at a time, one batch ahead of the taps that consume them:
-        // with a single window in flight every event waited out a full L2 round trip (49 us of
-        // latency for 25 us of issue, profiles/r02)
-        float dy_n[CB_PF];
-        int ps_n[CB_PF];
-#pragma unroll
-        for (int q = 0; q < CB_PF; ++q) {
-            const int off = min(wc + q, wend - 1) * Bs + b;       // 32-bit lane offset, uniform base
-            dy_n[q] = dyu[off];
-            ps_n[q] = (int)idxu[off];
-        }
-        for (int wb0 = wc; wb0 < wend; wb0 += CB_PF) {
-        float dy_c[CB_PF];
-        int ps_c[CB_PF];
-#pragma unroll
-        for (int q = 0; q < CB_PF; ++q) { KEEP(dy_n[q]); KEEP(ps_n[q]); dy_c[q] = dy_n[q]; ps_c[q] = ps_n[q]; }
-#pragma unroll
-        for (int q = 0; q < CB_PF; ++q) {
-            const int off = min(wb0 + CB_PF + q, wend - 1) * Bs + b;
-            dy_n[q] = dyu[off];
-            ps_n[q] = (int)idxu[off];
-        }
-#pragma unroll
-        for (int q = 0; q < CB_PF; ++q) {
-            const int wb = wb0 + q;
-            float dyv = (wb < wend) ? dy_c[q] : 0.f;
-            const int ps = ps_c[q] + POOLW * min(wb, wend - 1);
-            // lanes past the batch (the last, partly filled tile) must not contribute: their dy is
-            // whatever an earlier, larger batch left there
-            dyv = (b < B) ? dyv : 0.f;
-            const int w0 = (ps >> 4) - w_lo, sh = (ps & 15) * 2;
-            const uint32_t c0 = pks[w0 * 64 + lane], c1 = pks[(w0 + 1) * 64 + lane],
-                           c2 = pks[(w0 + 2) * 64 + lane];
-            const uint32_t lo = __funnelshift_r(c0, c1, sh), hi = __funnelshift_r(c1, c2, sh);
-            const int n0 = (ps >> 5) - n_lo, nsh = ps & 31;
-            uint32_t nm = __funnelshift_r(nms[n0 * 64 + lane], nms[(n0 + 1) * 64 + lane], nsh) & KMASK;
-            const f32x2 dy2 = f32x2{dyv, dyv};
-            // rows are fetched five at a time, one group ahead of the sums that consume them (all K
-            // in flight would need 4K registers; one group at a time left the LDS latency exposed
-            // four times per window)
-            auto row_addr = [&](int j) -> uint32_t {
-                // byte offset of the code's one-hot row: code * 16
-                const uint32_t off16 = j < 16 ? ((j >= 2 ? (lo >> (2 * j - 4)) : (lo << (4 - 2 * j))) & 0x30u)
-                                              : ((j >= 18 ? (hi >> (2 * (j - 16) - 4)) : (hi << (4 - 2 * (j - 16)))) & 0x30u);
-                return off16 | ohbase;
-            };
-            constexpr int NGRP = (K + 4) / 5;
-            f32x4b r[2][5];
-#pragma unroll
-            for (int jj = 0; jj < 5; ++jj)
-                if (jj < K) r[0][jj] = *(const volatile lds_f32x4*)(size_t)row_addr(jj);
-#pragma unroll
-            for (int gq = 0; gq < NGRP; ++gq) {
-                const int j0 = 5 * gq;
-                if (gq + 1 < NGRP) {
-#pragma unroll
-                    for (int jj = 0; jj < 5; ++jj)
-                        if (j0 + 5 + jj < K)
-                            // (volatile: the fourth component is unused and a narrowed ds_read_b96
-                            // costs twice the LDS cycles of the b128)
-                            r[(gq + 1) & 1][jj] = *(const volatile lds_f32x4*)(size_t)row_addr(j0 + 5 + jj);
-                }
-#pragma unroll
-                for (int jj = 0; jj < 5; ++jj) {
-                    const int j = j0 + jj;
-                    if (j < K) {
-                        a12[j] = __builtin_elementwise_fma(dy2, f32x2{r[gq & 1][jj][0], r[gq & 1][jj][1]}, a12[j]);
-                        a3[j] = fmaf(dyv, r[gq & 1][jj][2], a3[j]);
-                        // pinned here: otherwise the sums sink below the N loop into the loop latch
-                        // and all K rows (4K registers) stay live across it
-                        KEEP(a12[j]); KEEP(a3[j]);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            tot += dyv;
-            // N bases (packed as 'C'): the few lanes that have one add that dy to the tap's LDS cell
-            while (__any(nm != 0u)) {
-                if (nm != 0u) {
-                    const int j = __ffs(nm) - 1;
-                    nm &= nm - 1u;
-                    atomicAdd(&nlds[j], dyv);
-                }
-            }
-        }
-        }
-    }
-    }
-    STAMP(2);
-    // sums over the 64 lanes through LDS, one base at a time: every lane parks K values as a column
-    // of a [K][65] tile (the code tiles are dead by now), then lane j adds up row j
-    float* red = reinterpret_cast<float*>(smem) + 16;
-    float* out = Dspp + ((size_t)u * (Bs / 32) + blockIdx.x) * 4 * K;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-            const float v = a == 0 ? (tot - a12[j][0] - a12[j][1] - a3[j]) : (a == 1 ? a12[j][0] : (a == 2 ? a12[j][1] : a3[j]));
-            red[j * 65 + lane] = v;
-        }
-        __syncthreads();
-        if (lane < K) {
-            float sacc = 0.f;
-#pragma unroll 16
-            for (int l = 0; l < 64; ++l) sacc += red[lane * 65 + l];
-            if (a == 1) sacc -= nlds[lane];            // lane j holds tap j: take its N sum out
-            out[a * K + lane] = sacc;
-        }
-    }
-    STAMP(3);
 }
 
 #define KB_DISPATCH(Kv, CALL)                                                                  \
@@ -653,19 +491,34 @@ __global__ __launch_bounds__(64, 3) void conv_bwd_kernel(const float* __restrict
 typedef __attribute__((ext_vector_type(8))) __bf16 cb_bf16x8;
 typedef uint32_t cb_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short cb_u16x2 __attribute__((ext_vector_type(2)));
-#define CBM_CHUNK 32                  // pooling windows per LDS image of the expanded masks
-__host__ __device__ constexpr int cbm_tiles(int K) { return (4 * K + 15) / 16; }
+#define CBM_CHUNK 14                  // pooling windows per LDS image of the expanded masks (even: parity)
+#define CBM_WAVES 4                   // wavefronts per workgroup (one per SIMD): they take the windows of a chunk in turn
+#ifndef CBM_PF
+#define CBM_PF 1                      // windows of dy / idx a wave keeps in flight (2 and 3 measured slower)
+#endif
+__host__ __device__ constexpr int cbm_tiles(int K) { return (K + 3) / 4; }   // 16-column tiles = 4 taps x 4 bases
+// waves per SIMD the register budget is held to: accumulators and B fragments grow with the tile count
+__host__ __device__ constexpr int cbm_occ(int K) { return cbm_tiles(K) <= 5 ? 4 : (cbm_tiles(K) <= 6 ? 3 : 2); }
 
+// Geometry: workgroup = (block of 32 sequences, tile of 16 units, half of the pooling windows), four
+// wavefronts = one per SIMD, so a CU's SIMDs always hold equal shares.  At C2 that is 1216 workgroups
+// of 28 KB of LDS; the kernel is held to 128 registers so that four are resident per CU (4 waves per
+// SIMD) and the dispatcher hands the remaining ones to whichever CU finishes first.  What the stamps
+// showed about the alternatives (tools/stampbench, profiles/r03): the main loop saturates the matrix
+// pipe, so the time is set by the SIMD with the most waves -- 608 four-wave workgroups over all
+// windows (three per CU at 51 KB) and 1216 two-wave ones (2-3 waves per SIMD) both left SIMDs with
+// 3 x 10.9 K cycles of MFMA work where the average is 2.4 x.
 template <int K>
-__global__ __launch_bounds__(256, 3) void conv_bwd_mm_kernel(
+__global__ __launch_bounds__(64 * CBM_WAVES, cbm_occ(K)) void conv_bwd_mm_kernel(
     const float* __restrict__ dy, const uint8_t* __restrict__ idx,
     const unsigned long long* __restrict__ bm, float* __restrict__ Dspp, int U, int n, int Bs, int B,
-    int NT64, int Lp, int LQ, int NP) {
-    constexpr int K4 = 4 * K, NTL = cbm_tiles(K);
+    int NT64, int Lp, int NP, int wper) {
+    constexpr int K4 = 4 * K, NTL = cbm_tiles(K), NTH = 64 * CBM_WAVES;
     extern __shared__ __attribute__((aligned(16))) unsigned char cbsm[];
-    cb_u32x4* X = reinterpret_cast<cb_u32x4*>(cbsm);           // [LQ positions][4 bases][4 slots] x 16 bytes
+    cb_u32x4* X = reinterpret_cast<cb_u32x4*>(cbsm);           // [positions][4 bases][4 slots] x 16 bytes
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
     const int b0 = blockIdx.x * 32, u0 = blockIdx.y * 16;
+    const int wlo = blockIdx.z * wper, whi = min(n, wlo + wper);   // this workgroup's windows
     const int tile64 = b0 >> 6, half = (b0 >> 5) & 1;
     const int ua = min(u0 + c, U - 1);                          // the unit this lane feeds as an A row
     // sequences past the batch: their idx bytes are forced to 7, which no position matches
@@ -691,37 +544,58 @@ __global__ __launch_bounds__(256, 3) void conv_bwd_mm_kernel(
     for (int t = 0; t < NTL; ++t) acc[t] = f32x4b{0.f, 0.f, 0.f, 0.f};
     const float* __restrict__ dyu = dy + (size_t)ua * n * Bs + b0 + 8 * g;
     const uint8_t* __restrict__ ixu = idx + (size_t)ua * n * Bs + b0 + 8 * g;
+    typedef __attribute__((address_space(3))) cb_u32x4 lds_u32x4;
+    typedef __attribute__((address_space(3))) unsigned char lds_uchar;
+    const uint32_t xlds = (uint32_t)(size_t)(const lds_uchar*)cbsm;
     STAMP(0);
-    for (int wc = 0; wc < n; wc += CBM_CHUNK) {
-        const int nwin = min(CBM_CHUNK, n - wc), q0 = POOLW * wc, nq = POOLW * nwin + K - 1;
-        // this wave's first window of the chunk: its loads fly while the masks are expanded
+    for (int wc = wlo; wc < whi; wc += CBM_CHUNK) {
+        const int nwin = min(CBM_CHUNK, whi - wc), q0 = POOLW * wc, nq = POOLW * nwin + K - 1;
+        // this wave's first CBM_PF windows of the chunk: their loads fly while the masks are expanded
+        // (one window ahead is enough: 29.4 us in-pipeline at C2 against 30.6 with two and 32.0 with
+        // three ahead -- the deeper queues only make the burst at kernel start larger)
         int w = wc + wave;
-        float4 d0 = make_float4(0.f, 0.f, 0.f, 0.f), d1 = d0;
-        uint2 iw = make_uint2(0u, 0u);
-        if (w < wc + nwin) {
-            d0 = *reinterpret_cast<const float4*>(dyu + (size_t)w * Bs);
-            d1 = *reinterpret_cast<const float4*>(dyu + (size_t)w * Bs + 4);
-            iw = *reinterpret_cast<const uint2*>(ixu + (size_t)w * Bs);
+        float4 qd0[CBM_PF], qd1[CBM_PF];
+        uint2 qiw[CBM_PF];
+#pragma unroll
+        for (int f = 0; f < CBM_PF; ++f) {
+            const int wf = min(w + f * CBM_WAVES, wc + nwin - 1);
+            qd0[f] = *reinterpret_cast<const float4*>(dyu + (size_t)wf * Bs);
+            qd1[f] = *reinterpret_cast<const float4*>(dyu + (size_t)wf * Bs + 4);
+            qiw[f] = *reinterpret_cast<const uint2*>(ixu + (size_t)wf * Bs);
         }
         __syncthreads();                                        // the previous chunk's X is dead
-        for (int e = tid; e < 4 * nq; e += 256) {
-            const int a = e / nq, q = e - a * nq;
-            const unsigned long long m = bm[((size_t)a * NT64 + tile64) * Lp + q0 + q];
-            const uint32_t bits32 = half ? (uint32_t)(m >> 32) : (uint32_t)m;
+        // (every mask word of this thread is requested before the first is expanded: one load per
+        // loop turn exposed a memory round trip each, 8 K of the kernel's 43 K cycles per wave)
+        constexpr int XIT = (4 * (POOLW * CBM_CHUNK + K - 1) + NTH - 1) / NTH;
+        unsigned long long mw[XIT];
 #pragma unroll
-            for (int gg = 0; gg < 4; ++gg) {
-                const uint32_t by = (bits32 >> (8 * gg)) & 0xffu;
-                cb_u32x4 v;
+        for (int it = 0; it < XIT; ++it) {
+            const int e = min(tid + it * NTH, 4 * nq - 1);
+            mw[it] = bm[((size_t)(e & 3) * NT64 + tile64) * Lp + q0 + (e >> 2)];
+        }
 #pragma unroll
-                for (int d = 0; d < 4; ++d)
-                    v[d] = ((by >> (2 * d)) & 1u) * 0x00003f80u + ((by >> (2 * d + 1)) & 1u) * 0x3f800000u;
-                X[(q * 4 + a) * 4 + (gg ^ ((q & 1) << 1))] = v;
+        for (int it = 0; it < XIT; ++it) {
+            const int e = tid + it * NTH;
+            if (e < 4 * nq) {
+                const int q = e >> 2, a = e & 3;                 // (position, base): 64 contiguous bytes each
+                const uint32_t bits32 = half ? (uint32_t)(mw[it] >> 32) : (uint32_t)mw[it];
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {
+                    const uint32_t by = (bits32 >> (8 * gg)) & 0xffu;
+                    cb_u32x4 v;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d)
+                        v[d] = ((by >> (2 * d)) & 1u) * 0x00003f80u + ((by >> (2 * d + 1)) & 1u) * 0x3f800000u;
+                    X[(q * 4 + a) * 4 + (gg ^ ((q & 1) << 1))] = v;
+                }
             }
         }
         __syncthreads();
-        if (wc == 0) STAMP(1);
-        for (; w < wc + nwin; w += 4) {
+        if (wc == wlo) STAMP(1);
+        for (; w < wc + nwin; w += CBM_WAVES) {
             // pieces of the 8 gradients: x = hi + mid + lo exactly, each piece a bf16
+            const float4 d0 = qd0[0], d1 = qd1[0];
+            const uint2 iw = qiw[0];
             const float xs[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
             uint32_t ph[4], pm[4], pl[4];
             {
@@ -749,130 +623,156 @@ __global__ __launch_bounds__(256, 3) void conv_bwd_mm_kernel(
             ip[1] = (1u << ((i0 >> 16) & 0xffu)) | (0x10000u << (i0 >> 24));
             ip[2] = (1u << (i1 & 0xffu)) | (0x10000u << ((i1 >> 8) & 0xffu));
             ip[3] = (1u << ((i1 >> 16) & 0xffu)) | (0x10000u << (i1 >> 24));
-            const int wn = w + 4;                               // next window of this wave: in flight below
-            if (wn < wc + nwin) {
-                d0 = *reinterpret_cast<const float4*>(dyu + (size_t)wn * Bs);
-                d1 = *reinterpret_cast<const float4*>(dyu + (size_t)wn * Bs + 4);
-                iw = *reinterpret_cast<const uint2*>(ixu + (size_t)wn * Bs);
+            // the queue moves up one and the window CBM_PF turns ahead is requested
+#pragma unroll
+            for (int f = 0; f + 1 < CBM_PF; ++f) { qd0[f] = qd0[f + 1]; qd1[f] = qd1[f + 1]; qiw[f] = qiw[f + 1]; }
+            {
+                const int wn = min(w + CBM_PF * CBM_WAVES, wc + nwin - 1);
+                qd0[CBM_PF - 1] = *reinterpret_cast<const float4*>(dyu + (size_t)wn * Bs);
+                qd1[CBM_PF - 1] = *reinterpret_cast<const float4*>(dyu + (size_t)wn * Bs + 4);
+                qiw[CBM_PF - 1] = *reinterpret_cast<const uint2*>(ixu + (size_t)wn * Bs);
             }
-            const uint32_t wbase = (uint32_t)(POOLW * (w - wc) * 256);
-            const uint32_t wpar = (uint32_t)((w - wc) & 1) << 5;   // parity of this window's first position
-            typedef __attribute__((address_space(3))) cb_u32x4 lds_u32x4;
-            typedef __attribute__((address_space(3))) unsigned char lds_uchar;
-            const uint32_t xbase = (uint32_t)(size_t)(const lds_uchar*)cbsm + wbase;
+            // parity of this window's first position (the chunk starts on an even one: 7 * 14 windows)
+            const uint32_t xbase = xlds + (uint32_t)(POOLW * (w - wc) * 256);
+            const uint32_t wpar = (uint32_t)((w - wc) & 1) << 5;
+            // A fragments of position r: the pieces where the offset equals r (0xffff per half whose
+            // bit r is set).  The fragments of position r + 1 are built IN PLACE while the MFMAs of
+            // position r run, each piece as soon as the matrix instructions that read it have issued
+            // (hi is rewritten under the mid MFMAs, mid under the lo ones, lo at the end), with the
+            // mask words computed under the hi MFMAs.  sched_barrier after every step pins that order:
+            // a wave issues in order, so vector work behind a block of back-to-back MFMAs would find
+            // the matrix pipe idle and vector work in front of it the vector pipe.
+            cb_u32x4 ah, am, al;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const uint32_t mk = __umul24(ip[d] & 0x00010001u, 0xffffu);
+                ah[d] = ph[d] & mk; am[d] = pm[d] & mk; al[d] = pl[d] & mk;
+            }
 #pragma unroll
             for (int r = 0; r < POOLW; ++r) {
-                cb_u32x4 ah, am, al;
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    // 0xffff per half whose bit r is set
-                    const uint32_t mk = __umul24((ip[d] >> r) & 0x00010001u, 0xffffu);
-                    ah[d] = ph[d] & mk; am[d] = pm[d] & mk; al[d] = pl[d] & mk;
-                }
-                const cb_bf16x8 fh = __builtin_bit_cast(cb_bf16x8, ah), fm = __builtin_bit_cast(cb_bf16x8, am),
-                                fl = __builtin_bit_cast(cb_bf16x8, al);
                 cb_bf16x8 fb[NTL];
 #pragma unroll
                 for (int t = 0; t < NTL; ++t)
                     fb[t] = __builtin_bit_cast(cb_bf16x8, *(const lds_u32x4*)(size_t)(
                         xbase + ((boff[t] ^ wpar ^ (uint32_t)((r & 1) << 5)) + (uint32_t)(r * 256))));
-                // piece outermost: consecutive MFMAs go to different accumulators
+                uint32_t tz[4] = {0u, 0u, 0u, 0u};
+                const bool more = r + 1 < POOLW;
+                __builtin_amdgcn_sched_barrier(0);
+                // hi piece; the four mask words of the next position (3 instructions each) in between
 #pragma unroll
-                for (int t = 0; t < NTL; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh, fb[t], acc[t], 0, 0, 0);
+                for (int t = 0; t < NTL; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cb_bf16x8, ah), fb[t], acc[t], 0, 0, 0);
+                    if (more) {
 #pragma unroll
-                for (int t = 0; t < NTL; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fm, fb[t], acc[t], 0, 0, 0);
+                        for (int k = (12 * t) / NTL; k < (12 * (t + 1)) / NTL; ++k) {
+                            const int d = k / 3, op = k - 3 * d;
+                            if (op == 0) tz[d] = ip[d] >> (r + 1);
+                            else if (op == 1) tz[d] &= 0x00010001u;
+                            else tz[d] = __umul24(tz[d], 0xffffu);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // mid piece; hi of the next position is rewritten in between
 #pragma unroll
-                for (int t = 0; t < NTL; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl, fb[t], acc[t], 0, 0, 0);
+                for (int t = 0; t < NTL; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cb_bf16x8, am), fb[t], acc[t], 0, 0, 0);
+                    if (more) {
+#pragma unroll
+                        for (int d = (4 * t) / NTL; d < (4 * (t + 1)) / NTL; ++d) ah[d] = ph[d] & tz[d];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // lo piece; mid of the next position in between, lo behind the last MFMA
+#pragma unroll
+                for (int t = 0; t < NTL; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cb_bf16x8, al), fb[t], acc[t], 0, 0, 0);
+                    if (more) {
+#pragma unroll
+                        for (int d = (4 * t) / NTL; d < (4 * (t + 1)) / NTL; ++d) am[d] = pm[d] & tz[d];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (more) {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) al[d] = pl[d] & tz[d];
+                }
             }
         }
     }
     STAMP(2);
-    // the four waves' tiles are added in a fixed order through LDS (the mask image is dead), then
-    // stored as ONE partial per (sequence block, unit): D[row = unit 4g + i][col c] of column tile t
+    // the waves' tiles are added in a fixed order through LDS (the mask image is dead), then stored
+    // as ONE partial per (sequence block, window half, unit): D[row = unit 4g + i][col c] of tile t
     __syncthreads();
-    float* red = reinterpret_cast<float*>(cbsm);                // [4 waves][NTL][4][64]
+    float* red = reinterpret_cast<float*>(cbsm);                // [waves][NTL][4][64]
 #pragma unroll
     for (int t = 0; t < NTL; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) red[((wave * NTL + t) * 4 + i) * 64 + lane] = acc[t][i];
     __syncthreads();
-    for (int e = tid; e < NTL * 4 * 64; e += 256) {
-        const float v = ((red[e] + red[NTL * 256 + e]) + red[2 * NTL * 256 + e]) + red[3 * NTL * 256 + e];
+    const int part = blockIdx.z * gridDim.x + blockIdx.x;
+    for (int e = tid; e < NTL * 4 * 64; e += NTH) {
+        float v = red[e];
+#pragma unroll
+        for (int wv = 1; wv < CBM_WAVES; ++wv) v += red[wv * NTL * 256 + e];
         const int l = e & 63, i = (e >> 6) & 3, t = e >> 8;
         const int u = u0 + 4 * (l >> 4) + i, j = 4 * t + ((l & 15) >> 2), a = l & 3;
-        if (u < U && j < K) Dspp[((size_t)u * NP + blockIdx.x) * K4 + a * K + j] = v;
+        if (u < U && j < K) Dspp[((size_t)u * NP + part) * K4 + a * K + j] = v;
     }
     STAMP(3);
 }
 
-static size_t conv_bwd_mm_lds(const explainn_ctx* c, int* lq_out) {
-    const int nwin = c->n < CBM_CHUNK ? c->n : CBM_CHUNK;
-    const int LQ = POOLW * nwin + c->k - 1;
-    if (lq_out) *lq_out = LQ;
-    size_t sm = (size_t)4 * LQ * 64;
-    const size_t red = (size_t)4 * cbm_tiles(c->k) * 256 * sizeof(float);
+// windows per workgroup: the pooling windows are cut in two halves (one workgroup each) when there
+// are enough of them
+static int conv_bwd_mm_split(const explainn_ctx* c) {
+    int P = c->n >= 8 ? 2 : 1;
+    if (const char* e = getenv("EXPLAINN_CBM_SPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 8 && v <= c->n) P = v; }
+    return P;
+}
+static size_t conv_bwd_mm_lds(const explainn_ctx* c) {
+    const int wper = (c->n + conv_bwd_mm_split(c) - 1) / conv_bwd_mm_split(c);
+    const int nwin = wper < CBM_CHUNK ? wper : CBM_CHUNK;
+    const size_t sm = (size_t)(POOLW * nwin + c->k - 1) * 256;
+    const size_t red = (size_t)CBM_WAVES * cbm_tiles(c->k) * 256 * sizeof(float);
     return sm > red ? sm : red;
 }
 
 int launch_conv_bwd_mm(explainn_ctx* c, int B, hipStream_t s) {
-    int LQ = 0;
-    const size_t sm = conv_bwd_mm_lds(c, &LQ);
-    const int NP = (B + 31) / 32;
-    const dim3 grid(NP, (c->U + 15) / 16);
+    const size_t sm = conv_bwd_mm_lds(c);
+    const int P = conv_bwd_mm_split(c), wper = (c->n + P - 1) / P, NB = (B + 31) / 32;
+    const dim3 grid(NB, (c->U + 15) / 16, P);
 #define CALL(KK)                                                                                   \
-    hipLaunchKernelGGL(conv_bwd_mm_kernel<KK>, grid, dim3(256), sm, s, c->dy, c->idx, c->bm, c->Dspp, \
-                       c->U, c->n, c->Bs, B, (B + 63) / 64, c->Lp, LQ, c->Bs / 32)
+    hipLaunchKernelGGL(conv_bwd_mm_kernel<KK>, grid, dim3(64 * CBM_WAVES), sm, s, c->dy, c->idx, c->bm, \
+                       c->Dspp, c->U, c->n, c->Bs, B, (B + 63) / 64, c->Lp, c->Bs / 4, wper)
     KB_DISPATCH(c->k, CALL);
 #undef CALL
     LAUNCH_CHECK();
-    c->dsp_stride = c->Bs / 32; c->dsp_count = NP;
+    c->dsp_stride = c->Bs / 4; c->dsp_count = NB * P;
     return EXPLAINN_OK;
 }
 
-int launch_conv_bwd(explainn_ctx* c, int B, hipStream_t s) {
-    {   // A/B switch while both formulations exist (EXPLAINN_CONV_BWD=reg selects the register form)
-        const char* e = getenv("EXPLAINN_CONV_BWD");
-        if (!(e && e[0] == 'r')) return launch_conv_bwd_mm(c, B, s);
-    }
-    const dim3 grid(((B + 63) / 64 + CB_TILES - 1) / CB_TILES, c->U);
-    // chunk tiles (see the kernel: [PWC + NWC][64] words) or the [k][65] reduction tile
-    const int pwc = ((POOLW * 32 + c->k + 15) >> 4) + 2, nwc = ((POOLW * 32 + c->k + 31) >> 5) + 2;
-    size_t sm = (size_t)(pwc + nwc) * 64 * sizeof(uint32_t);
-    const size_t red_bytes = (size_t)c->k * 65 * sizeof(float);
-    if (sm < red_bytes) sm = red_bytes;
-    sm += 4 * sizeof(float4);                          // the one-hot rows in front of the tiles
-    const int nlds_off = (int)(sm / sizeof(float));    // k floats behind the tiles: the N corrections
-    sm += (size_t)((c->k + 15) & ~15) * sizeof(float);
-#define CALL(KK)                                                                               \
-    hipLaunchKernelGGL(conv_bwd_kernel<KK>, grid, dim3(64), sm, s, c->dy, c->idx, c->pk2, c->nmask, \
-                       c->Dspp, c->U, c->n, c->Bs, c->PW, c->NW, nlds_off, B)
-    KB_DISPATCH(c->k, CALL);
-#undef CALL
-    LAUNCH_CHECK();
-    c->dsp_stride = c->Bs / 32; c->dsp_count = (int)grid.x;
-    return EXPLAINN_OK;
-}
+int launch_conv_bwd(explainn_ctx* c, int B, hipStream_t s) { return launch_conv_bwd_mm(c, B, s); }
 
 // ---------------------------------------------------------------------------------------------
 // One block per unit.  (Folding this into conv_bwd's last-arriving tile was tried: the device-scope
 // release every tile then needs -- an L2 write-back on this multi-XCD part -- cost 130 us per step.)
-__global__ __launch_bounds__(128) void fin_bwd_kernel(const fin_args fin,
-                                                      const float* __restrict__ Dspp, int Bs, int B) {
-    fin_unit(fin, Dspp, blockIdx.x, threadIdx.x, 128, Bs, B);
+__global__ __launch_bounds__(FIN_THREADS) void fin_bwd_kernel(const fin_args fin,
+                                                              const float* __restrict__ Dspp, int Bs, int B) {
+    fin_unit(fin, Dspp, blockIdx.x, threadIdx.x, FIN_THREADS, Bs, B);
 }
 
 int launch_fin_bwd(explainn_ctx* c, const explainn_params* p, const explainn_grads* g, int B,
                    int freeze_n, hipStream_t s) {
     const fin_args fin = {c->S12p, c->m, c->Gw, c->mug, c->sig1, p->bn1_w, g->conv_w, g->conv_b,
                           g->bn1_w, g->bn1_b, c->K4, freeze_n, fc_ng(c->NQ), c->dsp_stride, c->dsp_count};
-    hipLaunchKernelGGL(fin_bwd_kernel, dim3(c->U), dim3(128), 0, s, fin, c->Dspp, c->Bs, B);
+    hipLaunchKernelGGL(fin_bwd_kernel, dim3(c->U), dim3(FIN_THREADS), 0, s, fin, c->Dspp, c->Bs, B);
     LAUNCH_CHECK();
     return EXPLAINN_OK;
 }
 
 int bwd_configure(explainn_ctx* c) {
     {
-        const size_t sm = conv_bwd_mm_lds(c, nullptr);
+        const size_t sm = conv_bwd_mm_lds(c);
         if (sm > 48 * 1024) {
 #define CALL(KK)                                                                                  \
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bwd_mm_kernel<KK>),   \

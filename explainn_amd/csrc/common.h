@@ -16,7 +16,6 @@
 #define WAVE 64
 #define MAX_K 32          // kernel sizes instantiated for the conv kernels
 #define MAX_NQ 160        // largest pooled length with an instantiated FC kernel
-#define CB_TILES 2        // 64-sequence tiles per conv_bwd wavefront (one Dspp partial per CB_TILES tiles)
 
 struct explainn_ctx {
     int U, k, L, T, maxB, device;
@@ -83,7 +82,7 @@ struct explainn_ctx {
     float* k0p;           // [U][NS]
     float* dy;            // [U4][n][Bs]
     float* S12p;          // [U][NG][Bs/16][2] per (w-tile group, 16-sequence tile): sum dy, sum dy*chat
-    float* Dspp;          // [U][Bs/32][4k]     filter-gradient partials (one per 32-sequence block)
+    float* Dspp;          // [U][Bs/16][4k]     filter-gradient partials (one per 32-sequence block and window half)
     int dsp_stride, dsp_count;   // partial slots per unit / how many of them the last conv_bwd wrote
     float* dlogits;       // [maxB][T]         (train_step only)
     float* dlT;           // [T][Bs]   d loss / d logits, task-major (head GEMMs, T > HEAD_GEMM_MIN_T)

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void dense_conv_pool_kernel(const float* __res
 
 // one block per (unit, CB2 x 64 sequences); thread <-> filter entry (a, j); the dy / argmax rows of
 // a pooling window are staged through LDS, the x values come straight from global memory
-#define DENSE_BWD_SEQS (64 * CB_TILES)
+#define DENSE_BWD_SEQS 128                     // sequences per dense_conv_bwd block (one partial each)
 __global__ __launch_bounds__(128) void dense_conv_bwd_kernel(const float* __restrict__ x,
                                                              const float* __restrict__ dy,
                                                              const uint8_t* __restrict__ idx,
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(128) void dense_conv_bwd_kernel(const float* __rest
             }
         }
     }
-    if (mine) Dspp[((size_t)u * (Bs / 32) + blockIdx.x) * K4 + tid] = acc;
+    if (mine) Dspp[((size_t)u * (Bs / 4) + blockIdx.x) * K4 + tid] = acc;
 }
 
 __global__ __launch_bounds__(256) void dense_conv_act_kernel(const float* __restrict__ x,
@@ -223,7 +223,7 @@ int launch_dense_conv_bwd(explainn_ctx* c, const float* x, int B, hipStream_t s)
     hipLaunchKernelGGL(dense_conv_bwd_kernel, dim3((B + DENSE_BWD_SEQS - 1) / DENSE_BWD_SEQS, c->U),
                        dim3(128), 0, s, x, c->dy, c->idx, c->Dspp, c->k, c->L, c->n, c->Bs, B);
     LAUNCH_CHECK();
-    c->dsp_stride = c->Bs / 32; c->dsp_count = (B + DENSE_BWD_SEQS - 1) / DENSE_BWD_SEQS;
+    c->dsp_stride = c->Bs / 4; c->dsp_count = (B + DENSE_BWD_SEQS - 1) / DENSE_BWD_SEQS;
     return EXPLAINN_OK;
 }
 

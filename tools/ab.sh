@@ -4,9 +4,9 @@
 for v in "$@"; do
   if [ "$v" = base ]; then unset EXPLAINN_HIP_LIB; else export EXPLAINN_HIP_LIB="$PWD/$v"; fi
   echo -n "$v : "
-  python3 bench.py --no-cpu-baseline --skip-optimizer --steps 400 --warmup 30 2>/dev/null | python3 -c "
+  python3 bench.py --no-cpu-baseline --skip-optimizer --steps 400 --warmup 30 2>&1 | grep "^{" | python3 -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 k=d['roofline'].get('kernels') or {}
-print(d['ms_per_step'], {n:v['us'] for n,v in k.items() if n in ('fc_fwd','passB','passA','mid','conv_pool','conv_bwd')})"
+print(d['ms_per_step'], {n:v['us'] for n,v in k.items() if n in ('fc_fwd','passB','passA','mid','conv_pool','conv_bwd','fin_bwd','qmom','prep2')})"
 done

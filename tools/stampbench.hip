@@ -97,6 +97,7 @@ static void report(const char* name, int waves, int nst, float ms) {
 }
 
 int main() {
+    setvbuf(stdout, nullptr, _IOLBF, 0);      // a faulting kernel must not take the earlier reports with it
     const int U = 300, n = 26, B = 1024, Bs = 1088, NQ = 26, NS = ns_stride(NQ), NKS = 13, QCH = 8, ACH = 4, NK4Q = fc_nk4q(NQ), NW16 = fc_nw16(NQ);
     auto dalloc = [](size_t bytes) { void* p; CK(hipMalloc(&p, bytes)); CK(hipMemset(p, 0, bytes)); return p; };
     float* ext = (float*)dalloc((size_t)U * n * Bs * 4); float* alpha = (float*)dalloc(U * 4); float* shift = (float*)dalloc(U * 4);
@@ -124,7 +125,7 @@ int main() {
         if (rep) report("qmom", QCH * U, 4, ms);
         clear_stamps();
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((fc_fwd_bf_kernel<26, 2>), dim3(4, U), dim3(256), fc_fwd_bf_lds<26>(), 0, ext, alpha, shift, A2h, sh2, V2, bits, z, (const uint8_t*)nullptr, 19661u, 1.4285715f, 1u, 2u, fz, fz, fz, fz, fz, o, n, Bs, B, U, z12p);
+        hipLaunchKernelGGL((fc_fwd_bf_kernel<26, 2>), dim3(4, units_grid(U)), dim3(256), fc_fwd_bf_lds<26>(), 0, ext, alpha, shift, A2h, sh2, V2, bits, z, (const uint8_t*)nullptr, 19661u, 1.4285715f, 1u, 2u, fz, fz, fz, fz, fz, o, n, Bs, B, U, z12p);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
         if (rep) report("fc_fwd", 4 * U * 4, 5, ms);
         clear_stamps();
@@ -134,7 +135,7 @@ int main() {
         if (rep) report("passA", ACH * U * PA_WAVES, 4, ms);
         clear_stamps();
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(passB_kernel<26>, dim3(4, U, 1), dim3(256), passB_lds<26>(), 0, ext, alpha, shift, dz, bits, Tt, M, k0p, mug, sig1, dy, S12p, n, Bs, B); // (tables passed as fragment-ordered stand-ins)
+        hipLaunchKernelGGL(passB_kernel<26>, dim3(4, units_grid(U), 1), dim3(256), passB_lds<26>(), 0, ext, alpha, shift, dz, bits, Tt, M, k0p, mug, sig1, dy, S12p, n, Bs, B, U); // (tables passed as fragment-ordered stand-ins)
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
         if (rep) report("passB", 4 * U * 4, 6, ms);
     }
@@ -146,7 +147,7 @@ int main() {
         CK(hipMemcpy(pk2, hp.data(), hp.size() * 4, hipMemcpyHostToDevice));
         float* lut = (float*)dalloc((size_t)(U4 / 2) * NT * 32 * 4); float* Wt = (float*)dalloc((size_t)(U4 / 4) * k * 20 * 4);
         uint8_t* idx = (uint8_t*)dalloc((size_t)U * n * Bs);
-        float* Dspp = (float*)dalloc((size_t)U * (Bs / 64) * 76 * 4);
+        float* Dspp = (float*)dalloc((size_t)U * (Bs / 16) * 76 * 4);   // (partial stride Bs/16: common.h)
         float* fc1_w = (float*)dalloc((size_t)U * 100 * n * 4); float* VC = (float*)dalloc((size_t)U * 100 * NS * 4);
         double* qbar = (double*)dalloc((size_t)U * NS * 8); float* A2 = (float*)dalloc((size_t)U * 100 * NS * 4);
         float* sig2 = (float*)dalloc(U * 100 * 4); std::vector<float> ones(U * 100, 1.f); CK(hipMemcpy(sig2, ones.data(), U * 100 * 4, hipMemcpyHostToDevice));
@@ -158,11 +159,30 @@ int main() {
             hipLaunchKernelGGL((conv_pool_kernel<19, 8, true>), dim3(16 * 4, U4 / 4), dim3(64), cps, 0, pk2, nmask, (const float4*)lut, Wt, alpha, U, ext, idx, n, Bs, PW, NW, 4);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
             if (rep) report("conv_pool", 16 * 4 * (U4 / 4), 3, ms);
-            clear_stamps();
-            CK(hipEventRecord(e0));
-            hipLaunchKernelGGL(conv_bwd_kernel<19>, dim3(8, U), dim3(64), (size_t)(PW + NW) * 256 + 128 + 64, 0, dy, idx, pk2, nmask, Dspp, U, n, Bs, PW, NW, (PW + NW) * 64, B);
-            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
-            if (rep) report("conv_bwd", 8 * U, 4, ms);
+            {   // the matrix-core filter gradient: (32-sequence block, 16-unit tile, window half), two waves
+                static unsigned long long* bmask = nullptr; static float* Dmm = nullptr;
+                const int Lp = ((NW * 32 + 63) / 64) * 64, NT64 = (B + 63) / 64;
+                if (!bmask) {
+                    std::vector<unsigned long long> hb((size_t)4 * NT64 * Lp);
+                    for (auto& v : hb) v = ((unsigned long long)rand() << 33) ^ ((unsigned long long)rand() << 11) ^ rand();
+                    bmask = (unsigned long long*)dalloc(hb.size() * 8);
+                    CK(hipMemcpy(bmask, hb.data(), hb.size() * 8, hipMemcpyHostToDevice));
+                    Dmm = (float*)dalloc((size_t)U * (Bs / 16) * 76 * 4);
+                    std::vector<float> hd((size_t)U * n * Bs); for (auto& v : hd) v = (rand() % 2000) * 1e-3f - 1.f;
+                    CK(hipMemcpy(dy, hd.data(), hd.size() * 4, hipMemcpyHostToDevice));
+                    std::vector<uint8_t> hi((size_t)U * n * Bs); for (auto& v : hi) v = rand() % 7;
+                    CK(hipMemcpy(idx, hi.data(), hi.size(), hipMemcpyHostToDevice));
+                }
+                const int wper = (n + 1) / 2;
+                const size_t smm = (size_t)(7 * wper + 19 - 1) * 256;
+                clear_stamps();
+                CK(hipEventRecord(e0));
+                hipLaunchKernelGGL(conv_bwd_mm_kernel<19>, dim3((B + 31) / 32, (U + 15) / 16, 2), dim3(64 * CBM_WAVES), smm, 0,
+                                   dy, idx, bmask, Dmm, U, n, Bs, B, NT64, Lp, Bs / 16, wper);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+                CK(hipGetLastError());
+                if (rep) report("conv_bwd_mm", ((B + 31) / 32) * ((U + 15) / 16) * 2 * CBM_WAVES, 4, ms);
+            }
             clear_stamps();
             CK(hipEventRecord(e0));
             hipLaunchKernelGGL(prep2_kernel<true>, dim3(U), dim3(1024), prep2_lds(n, NS), 0, fc1_w, sh2, sh2, sh2, md, md + U * 100, (int64_t*)nullptr, qs0, S1p, S2p, qbar, VC, A2, (float*)nullptr, sh2, sig2, n, NS, NK4Q, B, QCH, A2h, fc_ks32(NQ));
