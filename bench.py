@@ -46,6 +46,13 @@ HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s 
 MFMA_F32_PEAK_TFLOPS = 157.3      # same guide: fp32 MFMA = fp32 vector rate
 LDS_PEAK_GBPS = 150000.0          # ds_read_b64/b128 aggregate
 CLOCK_HZ, SIMDS = 2.4e9, 1024
+MFMA_BF16_16x16x32_CLK = 16       # same guide: v_mfma_f32_16x16x32_bf16, cycles per SIMD
+# Measured here (tools/issue_rate.hip -> profiles/r03_issue_rate.txt), every SIMD of the chip holding
+# 4 waves: shader cycles one SIMD needs per wave-instruction.  Round 2 priced every vector
+# instruction at 4; the guide's 2-cycle figure holds for v_fma_f32 / v_xor_b32 only.
+ISSUE_CLK_PER_INST = {"v_fma_f32, v_xor_b32": 2.4, "other VALU (shifts, bfe, perm, and_or, add3, max, mul_u24, packed fp32)": 4.2,
+                      "v_cmp + v_cndmask pair (per instruction)": 3.3, "v_exp_f32": 8.1,
+                      "ds_read_b128": 16.4, "conv_pool instruction mix": 3.9}
 
 
 def launcher_command(argv, gpus, port=None, python=None):
@@ -212,8 +219,9 @@ def kernel_model(w, B):
         "passB": ("mfma_f32", 2.0 * (100 + n) * n * B * U),
         # LDS bytes the gather reads: one 8-byte dinucleotide row per (sequence, unit pair, position, tap pair)
         "conv_pool": ("lds", 8.0 * nt * Lo * B * U / 2),
-        # one 16-byte one-hot row per (sequence, unit, pooled position, tap)
-        "conv_bwd": ("lds", 16.0 * K * n * B * U),
+        # the filter gradient as a GEMM on the bf16 matrix core (csrc/bwd.hip): 3 exact pieces x
+        # ceil(k/4) column tiles per (32 sequences, 16 units, window, position)
+        "conv_bwd": ("mfma_bf16", 3.0 * ((K + 3) // 4) * ((B + 31) // 32) * ((U + 15) // 16) * n * 7),
     }
 
 
@@ -388,14 +396,26 @@ def main():
                     if kind == "mfma_f32":
                         ent.update(bound="mfma_f32", unpadded_gflop=round(work / 1e9, 3),
                                    mfma_frac=round(work / (us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4))
+                    elif kind == "mfma_bf16":
+                        # matrix-pipe time of the kernel's own MFMAs at the nominal clock / its duration
+                        roof_us = work * MFMA_BF16_16x16x32_CLK / SIMDS / CLOCK_HZ * 1e6
+                        ent.update(bound="mfma_bf16", mfma_instructions=int(work),
+                                   mfma_roof_us=round(roof_us, 2), mfma_frac=round(roof_us / us, 4))
                     else:
                         ent.update(bound="lds+valu", lds_gbytes=round(work / 1e9, 3),
                                    lds_frac=round(work / (us * 1e-6) / 1e9 / LDS_PEAK_GBPS, 4))
                 pc = (counters or {}).get("per_kernel", {}).get(name)
                 if pc:
-                    # VALU issue: SQ_INSTS_VALU wave-instructions x 4 cycles on 1024 SIMDs at 2.4 GHz
-                    if pc.get("SQ_INSTS_VALU"):
-                        ent["valu_frac"] = round(pc["SQ_INSTS_VALU"] * 4 / SIMDS / CLOCK_HZ / (us * 1e-6), 4)
+                    # vector pipe: measured busy time (SQ_ACTIVE_INST_VALU, quad-cycles summed over the
+                    # waves) per SIMD at the nominal clock / the kernel's duration; the instruction count
+                    # beside it gives the kernel's own cycles per vector instruction
+                    if pc.get("SQ_ACTIVE_INST_VALU"):
+                        ent["valu_frac"] = round(pc["SQ_ACTIVE_INST_VALU"] * 4 / SIMDS / CLOCK_HZ / (us * 1e-6), 4)
+                        if pc.get("SQ_INSTS_VALU"):
+                            ent["valu_clk_per_inst"] = round(pc["SQ_ACTIVE_INST_VALU"] * 4 / pc["SQ_INSTS_VALU"], 2)
+                    if pc.get("SQ_INSTS_LDS"):
+                        # LDS pipe: 4 array cycles per ds_read_b128 wave-instruction and CU (16 per SIMD)
+                        ent["lds_issue_frac"] = round(pc["SQ_INSTS_LDS"] * 16.4 / SIMDS / CLOCK_HZ / (us * 1e-6), 4)
                     if pc.get("hbm_bytes"):
                         ent["hbm_MB"] = round(pc["hbm_bytes"] / 1e6, 1)
                         ent["hbm_frac"] = round(pc["hbm_bytes"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
@@ -433,6 +453,7 @@ def main():
                          # with the fraction of the resource that binds it (this path is
                          # ~600-900 FLOP/B: no kernel is HBM-bound on algorithmic bytes)
                          "dominant_kernel": dominant,
+                         "issue_clk_per_inst": ISSUE_CLK_PER_INST,
                          "kernels": kernels,
                          "kernel_sum_us": round(sum(stage_us.values()), 1) if stage_us else None},
         }

@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (via gpurun) from the repo root: the bench line, the per-kernel trace and the
 # PMC passes that profiles/<tag>_* are copied from.   usage: bash tools/final_profile.sh r02_final [C2]
 set -e -o pipefail
-TAG=${1:-r02_final}
+TAG=${1:-r03_final}
 WL=${2:-C2}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG

@@ -30,13 +30,15 @@
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum { MIX_FMA, MIX_PK_FMA, MIX_PK_ADD, MIX_AND_OR, MIX_DS128, MIX_CONVPOOL, MIX_CONVBWD, MIX_EXP, MIX_COUNT };
+enum { MIX_FMA, MIX_PK_FMA, MIX_PK_ADD, MIX_AND_OR, MIX_DS128, MIX_CONVPOOL, MIX_CONVBWD, MIX_EXP,
+       MIX_XOR, MIX_LSHL, MIX_LSHL_ADD, MIX_CMP_CND, MIX_CND_VCC, MIX_MUL_U24, MIX_PERM, MIX_BFE, MIX_MAX, MIX_ADD3, MIX_COUNT };
 static const char* kMixName[MIX_COUNT] = {
     "v_fma_f32", "v_pk_fma_f32", "v_pk_add_f32", "v_and_or_b32", "ds_read_b128 (16 rows)",
     "conv_pool mix (bfe, and_or, ds128, 2 pk_add)", "conv_bwd mix (lshr, and_or, ds128, 2 pk_fma)",
-    "v_exp_f32"};
+    "v_exp_f32", "v_xor_b32 (VOP2)", "v_lshlrev_b32 (VOP2)", "v_lshl_add_u32 (VOP3)", "v_cmp_gt_f32 sgpr + v_cndmask_e64",
+    "v_cmp_gt_f32 vcc + v_cndmask_e32", "v_mul_u32_u24", "v_perm_b32", "v_bfe_u32", "v_max_f32", "v_add3_u32"};
 // wave-instructions per inner-loop body of each mix (what the rate is counted in)
-static const int kMixInsts[MIX_COUNT] = {128, 128, 128, 128, 64, 160, 160, 128};
+static const int kMixInsts[MIX_COUNT] = {128, 128, 128, 128, 64, 160, 160, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128};
 
 struct Rec { unsigned long long t0, t1, r0, r1, hw; };
 
@@ -87,6 +89,41 @@ __global__ __launch_bounds__(256) void issue_probe(Rec* rec, float* sink, int re
             for (int k = 0; k < 16; ++k)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+        } else if (MIX == MIX_XOR || MIX == MIX_LSHL || MIX == MIX_LSHL_ADD || MIX == MIX_MUL_U24 || MIX == MIX_PERM ||
+                   MIX == MIX_BFE || MIX == MIX_ADD3) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (MIX == MIX_XOR) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(u[i]) : "v"(m));
+                    else if (MIX == MIX_LSHL) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(u[i]));
+                    else if (MIX == MIX_LSHL_ADD) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(u[i]) : "v"(m));
+                    else if (MIX == MIX_MUL_U24) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(u[i]) : "v"(m));
+                    else if (MIX == MIX_PERM) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(m), "v"(base));
+                    else if (MIX == MIX_BFE) asm volatile("v_bfe_u32 %0, %0, 3, 8" : "+v"(u[i]));
+                    else asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(m), "v"(base));
+                }
+        } else if (MIX == MIX_MAX) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(x));
+        } else if (MIX == MIX_CMP_CND) {
+            // the ReLU / dropout select of the FC epilogues: a compare into an SGPR pair and a select on it
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    unsigned long long sm;
+                    asm volatile("v_cmp_gt_f32 %0, %1, %2" : "=s"(sm) : "v"(a[i]), "v"(x));
+                    asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(y), "s"(sm));
+                }
+        } else if (MIX == MIX_CND_VCC) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    asm volatile("v_cmp_gt_f32 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %3, vcc" : "+v"(a[i]) : "v"(a[i]), "v"(x), "v"(y) : "vcc");
         } else if (MIX == MIX_DS128) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
@@ -187,7 +224,7 @@ int main() {
     CK(hipMemset(rec, 0, (size_t)256 * 8 * 4 * sizeof(Rec)));
     CK(hipMalloc(&sink, (size_t)256 * 8 * 256 * sizeof(float)));
     const int reps = 500;
-    const int Ws[] = {1, 2, 4, 5, 8};
+    const int Ws[] = {1, 2, 4, 8};
     for (int W : Ws) {
         run<MIX_FMA>(W, rec, sink, reps);
         run<MIX_PK_FMA>(W, rec, sink, reps);
@@ -197,6 +234,16 @@ int main() {
         run<MIX_DS128>(W, rec, sink, reps);
         run<MIX_CONVPOOL>(W, rec, sink, reps);
         run<MIX_CONVBWD>(W, rec, sink, reps);
+        run<MIX_XOR>(W, rec, sink, reps);
+        run<MIX_LSHL>(W, rec, sink, reps);
+        run<MIX_LSHL_ADD>(W, rec, sink, reps);
+        run<MIX_BFE>(W, rec, sink, reps);
+        run<MIX_ADD3>(W, rec, sink, reps);
+        run<MIX_MUL_U24>(W, rec, sink, reps);
+        run<MIX_PERM>(W, rec, sink, reps);
+        run<MIX_MAX>(W, rec, sink, reps);
+        run<MIX_CMP_CND>(W, rec, sink, reps);
+        run<MIX_CND_VCC>(W, rec, sink, reps);
         printf("\n");
     }
     return 0;

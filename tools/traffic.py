@@ -24,7 +24,8 @@ STAGE = {"pack_tables_kernel": "pack_tables", "moments_kernel": "moments", "prep
          "prep2_kernel": "prep2", "fc_fwd_kernel": "fc_fwd", "fc_fwd_bf_kernel": "fc_fwd",
          "head_fwd_train_kernel": "head_fwd", "logits_kernel": "head_fwd", "logits_bn_kernel": "head_fwd", "loss_kernel": "loss", "head_bwd_kernel": "head_bwd",
          "passA_kernel": "passA", "mid_fused_kernel": "mid", "mid_big_kernel": "mid",
-         "passB_kernel": "passB", "conv_bwd_kernel": "conv_bwd", "fin_bwd_kernel": "fin_bwd",
+         "passB_kernel": "passB", "conv_bwd_kernel": "conv_bwd", "conv_bwd_mm_kernel": "conv_bwd",
+         "fin_bwd_kernel": "fin_bwd",
          "gemm32_kernel": "head_gemm"}
 
 
