@@ -215,9 +215,14 @@ __global__ __launch_bounds__(1024) void logits_bn_kernel(
     const bool owner = blockIdx.x == 0 && blockIdx.y == 0;
     for (int u = threadIdx.x; u < U; u += 1024) {
         double s1 = 0, s2 = 0;
-        for (int i = 0; i < nblk; ++i) {
-            s1 += z12p[((size_t)u * nblk + i) * 2];
-            s2 += z12p[((size_t)u * nblk + i) * 2 + 1];
+        for (int i0 = 0; i0 < nblk; i0 += 8) {           // eight partial pairs in flight per round trip
+            double2 pv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                pv[i] = *reinterpret_cast<const double2*>(&z12p[((size_t)u * nblk + min(i0 + i, nblk - 1)) * 2]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i0 + i < nblk) { s1 += pv[i].x; s2 += pv[i].y; }
         }
         const double mean = s1 / (double)B;
         const double var = fmax(s2 / (double)B - mean * mean, 0.0);
@@ -234,24 +239,33 @@ __global__ __launch_bounds__(1024) void logits_bn_kernel(
     const float* wr = Wf + (size_t)t * U;
     const bool store = t == 0 && b < B;
     float acc = 0.f;
-    for (int u0 = wv; u0 < U; u0 += 160) {             // ten units (twenty loads) in flight
-        float wq[10], zq[10];
+    // twenty units (forty loads) in flight per wave: the 300 units of the headline shape are one
+    // memory round trip per wave (ten at a time made two dependent ones in a kernel that is nothing
+    // but round trips)
+    constexpr int LQ = 20;
+    for (int u0 = wv; u0 < U; u0 += 16 * LQ) {
+        float wq[LQ], zq[LQ];
 #pragma unroll
-        for (int q = 0; q < 10; ++q) {
+        for (int q = 0; q < LQ; ++q) {
             const int u = min(u0 + 16 * q, U - 1);
             wq[q] = wr[u];
-            zq[q] = z[(size_t)u * Bs + b];
+            // (32-bit element offset from the uniform base: a 64-bit address per load took two
+            // registers each and spilled)
+            zq[q] = z[(uint32_t)u * (uint32_t)Bs + (uint32_t)b];
         }
 #pragma unroll
-        for (int q = 0; q < 10; ++q) { KEEP(wq[q]); KEEP(zq[q]); }
+        for (int q = 0; q < LQ; ++q) { KEEP(wq[q]); KEEP(zq[q]); }
 #pragma unroll
-        for (int q = 0; q < 10; ++q) {
+        for (int q = 0; q < LQ; ++q) {
             const int u = u0 + 16 * q;
             if (u < U) {                               // wave-uniform
                 const float4 sv = st4[u];
                 const float zh = (zq[q] - sv.x) * sv.y;
                 const float ov = fmaxf(fmaf(sv.z, zh, sv.w), 0.f);
-                if (store) { zhat[(size_t)u * Bs + b] = zh; o[(size_t)u * Bs + b] = ov; }
+                if (store) {
+                    const uint32_t off = (uint32_t)u * (uint32_t)Bs + (uint32_t)b;
+                    zhat[off] = zh; o[off] = ov;
+                }
                 acc = fmaf(wq[q], ov, acc);
             }
         }

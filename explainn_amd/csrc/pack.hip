@@ -16,6 +16,7 @@
 // in HBM at all -- optionally reverse-complemented on the fly (code' [p] = 3 - code[L-1-p], N stays
 // N: sequence/__init__.py:59-61 flips both axes of the one-hot).
 __device__ __forceinline__ int gridDim_x_tiles(int B) { return (B + 63) / 64; }
+#define PACK_WAVES 8        // wavefronts per pack block (64 sequences x 64 positions)
 
 template <bool CODES>
 __device__ __forceinline__ void pack_tile(const float* __restrict__ x,
@@ -32,15 +33,15 @@ __device__ __forceinline__ void pack_tile(const float* __restrict__ x,
     const int pc = min(p, L - 1);
     if (CODES) {
         const int ps = rc ? L - 1 - pc : pc;            // source position of output position p
-        for (int i0 = q; i0 < 64; i0 += 16) {
+        for (int i0 = q; i0 < 64; i0 += 4 * PACK_WAVES) {
             int v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = codes_in[(size_t)min(b0 + i0 + 4 * r, B - 1) * L + ps];
+            for (int r = 0; r < 4; ++r) v[r] = codes_in[(size_t)min(b0 + i0 + PACK_WAVES * r, B - 1) * L + ps];
 #pragma unroll
             for (int r = 0; r < 4; ++r) KEEP(v[r]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int i = i0 + 4 * r, b = b0 + i;
+                const int i = i0 + PACK_WAVES * r, b = b0 + i;
                 uint8_t code = 0;                       // padding lanes / past the end: see below
                 if (b < B && p < L) {
                     if (v[r] < 4) code = rc ? 3 - v[r] : v[r];
@@ -50,12 +51,14 @@ __device__ __forceinline__ void pack_tile(const float* __restrict__ x,
             }
         }
     } else {
-    // eight sequences (32 loads) per pass, all issued before any is used (see KEEP in common.h)
-    for (int i0 = q; i0 < 64; i0 += 32) {
+    // eight sequences (32 loads) per wave, all issued before any is used (see KEEP in common.h): with
+    // PACK_WAVES = 8 waves the tile's 64 sequences are ONE pass -- one memory round trip (four-wave
+    // blocks made two dependent ones; the 80 blocks of the headline shape are latency, not bandwidth)
+    for (int i0 = q; i0 < 64; i0 += 8 * PACK_WAVES) {
         float v[8][4];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            const int bc = min(b0 + i0 + 4 * r, B - 1);
+            const int bc = min(b0 + i0 + PACK_WAVES * r, B - 1);
             const float* xp = x + (size_t)bc * 4 * L + pc;
 #pragma unroll
             for (int a = 0; a < 4; ++a) v[r][a] = xp[(size_t)a * L];
@@ -66,7 +69,7 @@ __device__ __forceinline__ void pack_tile(const float* __restrict__ x,
             for (int a = 0; a < 4; ++a) KEEP(v[r][a]);
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            const int i = i0 + 4 * r, b = b0 + i;
+            const int i = i0 + PACK_WAVES * r, b = b0 + i;
             // padding lanes (b >= B) and positions past the end are 'A': nothing reads their results,
             // and as N they would drag their wavefront through the N corrections of the conv kernels
             uint8_t code = 0;
@@ -82,13 +85,14 @@ __device__ __forceinline__ void pack_tile(const float* __restrict__ x,
     }
     }
     __syncthreads();
-    for (int pp = q; pp < 64; pp += 4) {
+    for (int pp = q; pp < 64; pp += PACK_WAVES) {
         const int p = p0 + pp;
         if (p < L) codesT[(size_t)p * Bs + b0 + lane] = tile[lane][pp];
     }
-    // packed forms of the same tile: wave q packs positions [16q, 16q+16) into one 2-bit word per
-    // sequence; waves 0 and 1 also build the two 32-position N-mask words
-    {
+    // packed forms of the same tile: wave q < 4 packs positions [16q, 16q+16) into one 2-bit word per
+    // sequence; waves 0 and 1 also build the two 32-position N-mask words; waves 4..7 take the bit
+    // masks of positions [16(q-4), ...) below
+    if (q < 4) {
         uint32_t w2 = 0, nm = 0;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -108,7 +112,8 @@ __device__ __forceinline__ void pack_tile(const float* __restrict__ x,
     // "sequence 64*tile + b has base a at position p" -- one ballot per (position, base) of the
     // tile; the moment kernel counts base pairs with AND + popcount on them.  N and the padding
     // lanes set no bit.  Wave q takes positions [16q, 16q+16): lane 16a + i keeps ballot (a, i).
-    if (bm != nullptr) {
+    if (bm != nullptr && q >= PACK_WAVES - 4) {
+        const int q = (threadIdx.x >> 6) - (PACK_WAVES - 4);     // (the last four waves)
         const bool live = b0 + lane < B;
         unsigned long long mine = 0ull;
 #pragma unroll
@@ -127,7 +132,7 @@ __device__ __forceinline__ void pack_tile(const float* __restrict__ x,
 }
 
 template <bool CODES>
-__global__ __launch_bounds__(256) void pack_onehot_kernel(const float* __restrict__ x,
+__global__ __launch_bounds__(64 * PACK_WAVES) void pack_onehot_kernel(const float* __restrict__ x,
                                                           const uint8_t* __restrict__ codes_in,
                                                           int rc,
                                                           uint8_t* __restrict__ codesT,
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(256) void pack_onehot_kernel(const float* __restric
 // Train forward: the pack tiles and the per-unit filter tables (which depend only on the weights)
 // in ONE launch -- the first gx*gy blocks pack, the following U4 blocks build tables; every launch
 // saved is ~4.5 us of this latency-bound pipeline.
-__global__ __launch_bounds__(256) void pack_tables_kernel(const float* __restrict__ x,
+__global__ __launch_bounds__(64 * PACK_WAVES) void pack_tables_kernel(const float* __restrict__ x,
                                                           uint8_t* __restrict__ codesT,
                                                           uint32_t* __restrict__ pk2,
                                                           uint32_t* __restrict__ nmask, int B,
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(256) void pack_tables_kernel(const float* __restric
         pack_tile<false>(x, nullptr, 0, codesT, pk2, nmask, B, L, Bs, PW, NW, flags, blk % gx, blk / gx,
                          bm, Lp);
     else
-        filter_tables_unit(conv_w, Wt, lut, U, k, blk - gx * gy, threadIdx.x, 256, wsh);
+        filter_tables_unit(conv_w, Wt, lut, U, k, blk - gx * gy, threadIdx.x, 64 * PACK_WAVES, wsh);
 }
 
 // Input moments in ONE launch (round 1: 3800 thin ballot waves for the pair counts + a Gram kernel,
@@ -225,7 +230,7 @@ int launch_pack(explainn_ctx* c, const float* x, int B, bool counts, hipStream_t
     } else {
         c->staged_B = 0;
         // position tiles cover the padded tail too, so the packed words past L are written (as zeros)
-        hipLaunchKernelGGL(pack_onehot_kernel<false>, dim3(gb, (c->NW * 32 + 63) / 64), dim3(256), 0,
+        hipLaunchKernelGGL(pack_onehot_kernel<false>, dim3(gb, (c->NW * 32 + 63) / 64), dim3(64 * PACK_WAVES), 0,
                            s, x, (const uint8_t*)nullptr, 0, c->codesT, c->pk2, c->nmask, B, c->L,
                            c->Bs, c->PW, c->NW, c->flags, counts ? c->bm : nullptr, c->Lp);
         LAUNCH_CHECK();
@@ -237,7 +242,7 @@ int launch_pack_tables(explainn_ctx* c, const float* x, const explainn_params* p
                        hipStream_t s) {
     const int gx = (B + 63) / 64, gy = (c->NW * 32 + 63) / 64;
     c->staged_B = 0;
-    hipLaunchKernelGGL(pack_tables_kernel, dim3(gx * gy + c->U4), dim3(256), 0, s, x, c->codesT,
+    hipLaunchKernelGGL(pack_tables_kernel, dim3(gx * gy + c->U4), dim3(64 * PACK_WAVES), 0, s, x, c->codesT,
                        c->pk2, c->nmask, B, c->L, c->Bs, c->PW, c->NW, c->flags, gx, gy, p->conv_w,
                        c->Wt, c->lut, c->U, c->k, c->bm, c->Lp);
     LAUNCH_CHECK();
@@ -246,7 +251,7 @@ int launch_pack_tables(explainn_ctx* c, const float* x, const explainn_params* p
 
 int launch_pack_codes(explainn_ctx* c, const uint8_t* codes, int B, int rc, hipStream_t s) {
     hipLaunchKernelGGL(pack_onehot_kernel<true>, dim3((B + 63) / 64, (c->NW * 32 + 63) / 64),
-                       dim3(256), 0, s, (const float*)nullptr, codes, rc, c->codesT, c->pk2, c->nmask,
+                       dim3(64 * PACK_WAVES), 0, s, (const float*)nullptr, codes, rc, c->codesT, c->pk2, c->nmask,
                        B, c->L, c->Bs, c->PW, c->NW, c->flags, c->bm, c->Lp);
     LAUNCH_CHECK();
     c->staged_B = B;

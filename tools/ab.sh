@@ -8,5 +8,5 @@ for v in "$@"; do
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 k=d['roofline'].get('kernels') or {}
-print(d['ms_per_step'], {n:v['us'] for n,v in k.items() if n in ('fc_fwd','passB','passA','mid','conv_pool','conv_bwd','fin_bwd','qmom','prep2')})"
+print(d['ms_per_step'], ' '.join('%s %.1f' % (n, v['us']) for n, v in sorted(k.items())))"
 done
