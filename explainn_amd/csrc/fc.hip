@@ -38,35 +38,64 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
 }
 
 // Lane-local epilogue of one 16-channel tile: the lane holds channels r = 16t + 4g + j (j = 0..3) of ITS
-// sequence.  ReLU, dropout (MODE 2: counter-based generator, two 16-bit draws per xorshift step;
-// MODE 3: the caller's keep mask), the FC2 partial dot product (v2s = V2 * 1/(1-p): the dropout scale
-// is folded into the weights when they are staged) and the "relu' > 0 and kept" bits.
+// sequence.  ReLU, dropout (MODE 2: the built-in generator; MODE 3: the caller's keep mask), the FC2
+// partial dot product (v2s = V2 * 1/(1-p): the dropout scale is folded into the weights when they
+// are staged) and the "relu' > 0 and kept" bits.
+//
+// fc_fwd is bound by its vector instructions (10.1 M of them at C2, 19.6 us of vector-pipe time in
+// a 27.5 us kernel, profiles/r03_mid_*), three quarters of them this epilogue, so it is written for
+// instruction count, per channel:
+//   * the conditions live in SGPR pairs (one v_cmp each, combined on the scalar unit);
+//   * the accumulation zp += v2 * y runs under that mask as EXEC (s_and_saveexec / v_fmac /
+//     s_mov): one vector instruction instead of a select and an FMA -- the scalar instructions
+//     issue on their own port;
+//   * the bit is shifted into the lane's word by an add-with-carry that takes the mask as its
+//     carry-in (nib = nib + nib + bit): one instruction instead of a select and an or;
+//   * the generator is one 24-bit multiply-add per draw (below) instead of half a six-instruction
+//     xorshift step, and the 16-bit draw is compared in place (SDWA) as before.
+// 11 -> 5 vector instructions per channel.
+//
+// Generator (MODE 2): per (seed, sequence, lane quarter, unit) a linear congruential stream
+// s' = (s mod 2^24) * 0xFD43FD + 0xC39EC3 (full period 2^24: multiplier = 5 mod 8, odd increment), started from
+// a three-round integer hash of the key; the draw is bits 16..31 of the 32-bit multiply-add, i.e. the
+// top byte of the next state under the product's overflow byte -- the well-mixed end of an LCG.
+// Keep rate, scaling and independence across channels / sequences / units / seeds are measured by
+// tests/test_gpu_parity.py::test_builtin_dropout_generator_statistics on the mask itself.
+__device__ __forceinline__ void fmac_under_mask(float& acc, float a, float b, unsigned long long m) {
+    unsigned long long saved;
+    asm volatile("s_and_saveexec_b64 %0, %4\n\tv_fmac_f32 %1, %2, %3\n\ts_mov_b64 exec, %0"
+                 : "=&s"(saved), "+v"(acc) : "v"(a), "v"(b), "s"(m) : "scc");
+}
+__device__ __forceinline__ uint32_t shift_in_bit(uint32_t nib, unsigned long long m) {
+    unsigned long long cout;
+    asm volatile("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(nib), "=s"(cout) : "s"(m));
+    return nib;
+}
+
 template <int MODE>
 __device__ __forceinline__ void fc_epilogue_tile(const f32x4& acc, int t, int g, const float* v2s,
                                                  uint32_t& rs, uint32_t thresh16, const uint8_t* km,
                                                  float& zp, uint32_t (&words)[4]) {
     const float4 v2 = *reinterpret_cast<const float4*>(&v2s[16 * t + 4 * g]);
     const float v2a[4] = {v2.x, v2.y, v2.z, v2.w};
-    bool pos[4];
+    unsigned long long pm[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float y = acc[j];
-        pos[j] = y > 0.f;
+        pm[j] = __builtin_amdgcn_ballot_w64(y > 0.f);
         if (MODE == 2) {
-            uint32_t rnd;
-            if ((j & 1) == 0) { rs ^= rs << 13; rs ^= rs >> 17; rs ^= rs << 5; rnd = rs & 0xffffU; }
-            else rnd = rs >> 16;
-            pos[j] = pos[j] && (rnd >= thresh16);
+            rs = __umul24(rs, 0xFD43FDu) + 0xC39EC3u;
+            pm[j] &= __builtin_amdgcn_ballot_w64((rs >> 16) >= thresh16);
         } else if (MODE == 3) {
             const int r = 16 * t + 4 * g + j;
-            pos[j] = pos[j] && (km[r < FC_H ? r : 0] != 0);
+            pm[j] &= __builtin_amdgcn_ballot_w64(km[r < FC_H ? r : 0] != 0);
         }
-        zp = fmaf(v2a[j], pos[j] ? y : 0.f, zp);
+        fmac_under_mask(zp, v2a[j], y, pm[j]);
     }
-    // bit j of the nibble = pos[j]: shift-and-add-carry, one instruction per channel
+    // bit j of the nibble = channel 4g + j of the tile: shifted in from the top
     uint32_t nib = 0u;
 #pragma unroll
-    for (int j = 3; j >= 0; --j) nib = nib + nib + (pos[j] ? 1u : 0u);
+    for (int j = 3; j >= 0; --j) nib = shift_in_bit(nib, pm[j]);
     // channel r = 16t + 4g + j is bit (r & 31) of word r >> 5
     words[t >> 1] |= nib << (16 * (t & 1) + 4 * g);
 }
@@ -94,7 +123,7 @@ __device__ __forceinline__ void fc_zmom_finish(double s1, double s2, double* __r
 #ifndef PB_BTW
 #define PB_BTW 4                     // 16-sequence tiles per wavefront in passB
 #endif
-#define FC_AHEAD 3                   // A-fragment reads in flight ahead of their MFMAs in the bf16 fc_fwd
+#define FC_AHEAD 2                   // A-fragment reads in flight ahead of their MFMAs in the bf16 fc_fwd (3 spills one register at 96)
 
 // MODE: 0 eval, 1 train without dropout, 2 train + counter-based generator, 3 train + keep-mask
 template <int NQ, int MODE>
@@ -169,7 +198,7 @@ __global__ __launch_bounds__(64 * fc_fwd_waves(NQ)) void fc_fwd_kernel(
         uint32_t rs = 0;
         if (MODE == 2)
             rs = mix32(mix32(seed_lo ^ (uint32_t)(4 * b + g) * 0x9E3779B9U) ^
-                       mix32(seed_hi + (uint32_t)u)) | 1u;
+                       mix32(seed_hi + (uint32_t)u));
         const uint8_t* km = (MODE == 3) ? keep_mask + (size_t)min(b, B - 1) * FC_H * U + (size_t)u * FC_H
                                         : nullptr;
         if (it == 0) STAMP(2);
@@ -328,7 +357,7 @@ __global__ __launch_bounds__(64 * fc_fwd_waves(NQ), fc_ks32(NQ) == 1 ? 5 : 2) vo
         uint32_t rs = 0;
         if (MODE == 2)
             rs = mix32(mix32(seed_lo ^ (uint32_t)(4 * b + g) * 0x9E3779B9U) ^
-                       mix32(seed_hi + (uint32_t)u)) | 1u;
+                       mix32(seed_hi + (uint32_t)u));
         const uint8_t* km = (MODE == 3) ? keep_mask + (size_t)min(b, B - 1) * FC_H * U + (size_t)u * FC_H
                                         : nullptr;
         if (it == 0) STAMP(2);
