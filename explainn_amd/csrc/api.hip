@@ -48,8 +48,13 @@ void carve(explainn_ctx* c, Carver& cv) {
     cv.take(&c->Gw, U4 * K4);
     cv.take(&c->Wt, (int64_t)c->Uq * c->k * 20);
     cv.take(&c->lut, (int64_t)(c->U4 / 2) * ((c->k + 1) / 2) * 32);
-    cv.take(&c->ext, U4 * n * Bs);
-    cv.take(&c->idx, U4 * n * Bs);
+    cv.take(&c->Wf, (int64_t)conv_tiles_padded(c->U, c->k) * conv_ksteps(c->k) * 3 * 512);
+    cv.take(&c->Wsg, (int64_t)conv_tiles_padded(c->U, c->k) * 32);
+    // (rows up to whole unit groups of the filter-bank GEMM: its waves store their padding rows too)
+    const int64_t Upad = (int64_t)32 * conv_tiles_padded(c->U, c->k);
+    // (+ 64: the dump words behind the last row, see cpm_position)
+    cv.take(&c->ext, Upad * n * Bs + 64);
+    cv.take(&c->idx, Upad * n * Bs + 64);
     cv.take(&c->qs0, U * NS);
     cv.take(&c->qS1p, U * c->QCH * NS);
     cv.take(&c->qS2p, U * c->QCH * NS * NS);

@@ -52,6 +52,10 @@ struct explainn_ctx {
     double* Gw;           // [U4][4k]
     float* Wt;            // [Uq][k][5][4]    filter taps, unit-quad interleaved, code 4 -> 0
     float* lut;           // [U4/4][ceil(k/2)][16] float4: dinucleotide tables per unit quad
+    uint32_t* Wsg;        // [tiles32][2 k-halves][16]: 0x80000000 where the unit pools the minimum, in the
+                          // order a lane of the filter-bank GEMM holds its 16 rows
+    uint16_t* Wf;         // [tiles32 (padded to whole unit groups)][KS][3 pieces][64 lanes][8] bf16: the filters as
+                          // A fragments of v_mfma_f32_32x32x16_bf16 (k = 4 tap + base), sign(gamma1) folded in
     float* ext;           // [U4][n][Bs]      pooled extreme of the raw gather sum
     uint8_t* idx;         // [U4][n][Bs]      argmax offset 0..6 inside the pooling window
     float* qs0;           // [U][NS]          shift for the q moments (q of sequence 0)
@@ -233,11 +237,22 @@ __device__ __forceinline__ void stage_columns2(uint32_t* __restrict__ t1, const 
         if (i < rows2) t2[i * 64] = b[i];
 }
 
+// The filter bank as a GEMM (convpool.hip) on v_mfma_f32_32x32x16_bf16: k-steps of 16 (4 taps x 4
+// bases), 32-unit tiles, two tiles per wave while their fragments and three operand buffers fit
+__host__ __device__ inline int conv_ksteps(int k) { return (k + 3) / 4; }
+__host__ __device__ inline int conv_ut(int k) { return conv_ksteps(k) <= 5 ? 2 : 1; }
+__host__ __device__ inline int conv_tiles_padded(int U, int k) {
+    const int ut = conv_ut(k);
+    return (((U + 31) / 32 + ut - 1) / ut) * ut;
+}
+
 // The filter bank's lookup tables for unit u (all threads of the block call it): Wt (per-tap table,
 // unit-quad interleaved, entry 4 = N = zero) and lut (dinucleotide sums, unit-pair interleaved)
 // from the current filters.  wsh: 4*MAX_K floats of LDS.
 __device__ __forceinline__ void filter_tables_unit(const float* __restrict__ conv_w,
+                                                   const float* __restrict__ gamma1,
                                                    float* __restrict__ Wt, float* __restrict__ lut,
+                                                   uint16_t* __restrict__ Wf, uint32_t* __restrict__ Wsg,
                                                    int U, int k, int u, int tid, int nthreads,
                                                    float* wsh) {
     const int K4 = 4 * k;
@@ -259,6 +274,28 @@ __device__ __forceinline__ void filter_tables_unit(const float* __restrict__ con
             if (j < k) sum += wsh[((code4 >> (2 * i)) & 3) * k + j];
         }
         lut[(((size_t)(u >> 2) * NT + t) * 16 + code4) * 4 + (u & 3)] = sum;
+    }
+    // Wf: the unit's row of the A operand of the filter-bank GEMM (convpool.hip), k = 4 tap + base,
+    // as three bf16 pieces whose sum is the fp32 weight exactly.  The pooling direction is folded in:
+    // a unit with gamma1 < 0 pools the minimum, so its row is negated (exact) and the kernel takes the
+    // maximum for everybody and gives the sign back when it stores.
+    const int KS = conv_ksteps(k);
+    const float sgn = (u < U && gamma1[u] < 0.f) ? -1.f : 1.f;
+    // D row of unit u: 8 (r/4) + 4 kh + r%4 within its tile
+    if (tid == 0) Wsg[((u >> 5) * 2 + ((u >> 2) & 1)) * 16 + 4 * ((u & 31) >> 3) + (u & 3)] = sgn < 0.f ? 0x80000000u : 0u;
+    for (int kk = tid; kk < 16 * KS; kk += nthreads) {
+        const int j = kk >> 2, a = kk & 3;
+        const float wv = j < k ? sgn * wsh[a * k + j] : 0.f;
+        const uint32_t hb = __float_as_uint(wv) & 0xffff0000u;
+        const float r1 = wv - __uint_as_float(hb);
+        const uint32_t mb = __float_as_uint(r1) & 0xffff0000u;
+        const float r2 = r1 - __uint_as_float(mb);
+        // A fragment of v_mfma_f32_32x32x16_bf16: lane 32 (k/8 mod 2) + row, element k mod 8
+        const int ks = kk >> 4, lane = 32 * ((kk >> 3) & 1) + (u & 31), e = kk & 7;
+        uint16_t* dst = Wf + ((((size_t)(u >> 5) * KS + ks) * 3) * 64 + lane) * 8 + e;
+        dst[0] = (uint16_t)(hb >> 16);
+        dst[512] = (uint16_t)(mb >> 16);
+        dst[1024] = (uint16_t)(__float_as_uint(r2) >> 16);
     }
 }
 

@@ -25,7 +25,7 @@ FIELDS = {"TotalSGPRs": "sgpr", "VGPRs": "vgpr", "AGPRs": "agpr", "ScratchSize [
 # kernels one C2 training step launches (U = 300, k = 19, L = 200 -> n = 26, T = 1, B = 1024):
 # demangled-name patterns.  Templated kernels are matched on their C2 instantiation.
 C2_STEP = [
-    r"^pack_tables_kernel", r"^moments_kernel", r"^prep1_stats_kernel<true>", r"^conv_pool_kernel<19,",
+    r"^pack_tables_kernel", r"^moments_kernel", r"^prep1_stats_kernel<true>", r"^conv_pool_mm_kernel<5, 2,",
     r"^qmom_kernel<26>", r"^prep2_kernel<true>", r"^fc_fwd_bf_kernel<26, 2>", r"^logits_bn_kernel",
     r"^head_bwd_kernel<true, false>", r"^passA_kernel<26, false>", r"^mid_fused_kernel", r"^passB_kernel<26>",
     r"^conv_bwd_mm_kernel<19>", r"^fin_bwd_kernel", r"adam_kernel",
