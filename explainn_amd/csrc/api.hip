@@ -47,7 +47,6 @@ void carve(explainn_ctx* c, Carver& cv) {
     cv.take(&c->sig1, U4);
     cv.take(&c->Gw, U4 * K4);
     cv.take(&c->Wt, (int64_t)c->Uq * c->k * 20);
-    cv.take(&c->lut, (int64_t)(c->U4 / 2) * ((c->k + 1) / 2) * 32);
     cv.take(&c->Wf, (int64_t)conv_tiles_padded(c->U, c->k) * conv_ksteps(c->k) * 3 * 512);
     cv.take(&c->Wsg, (int64_t)conv_tiles_padded(c->U, c->k) * 32);
     // (rows up to whole unit groups of the filter-bank GEMM: its waves store their padding rows too)
@@ -224,7 +223,6 @@ extern "C" int explainn_create(explainn_ctx** out, int cnn_units, int kernel_siz
         TRY(prep_configure(c));
         TRY(bwd_configure(c));
         TRY(fc_configure(c));
-        TRY(conv_configure(c));
         return EXPLAINN_OK;
     }();
     if (rc != EXPLAINN_OK) { explainn_destroy(c); return rc; }

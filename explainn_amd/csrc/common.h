@@ -51,7 +51,6 @@ struct explainn_ctx {
     double* sig1;         // [U4]
     double* Gw;           // [U4][4k]
     float* Wt;            // [Uq][k][5][4]    filter taps, unit-quad interleaved, code 4 -> 0
-    float* lut;           // [U4/4][ceil(k/2)][16] float4: dinucleotide tables per unit quad
     uint32_t* Wsg;        // [tiles32][2 k-halves][16]: 0x80000000 where the unit pools the minimum, in the
                           // order a lane of the filter-bank GEMM holds its 16 rows
     uint16_t* Wf;         // [tiles32 (padded to whole unit groups)][KS][3 pieces][64 lanes][8] bf16: the filters as
@@ -173,7 +172,6 @@ int launch_dense_conv_act(explainn_ctx* c, const float* x, int B, float* acts, h
 int prep_configure(explainn_ctx* c);
 int bwd_configure(explainn_ctx* c);
 int fc_configure(explainn_ctx* c);
-int conv_configure(explainn_ctx* c);
 
 // In-kernel stamps (tools/stampbench.hip defines EXPLAINN_STAMP; the library build compiles them out)
 #ifdef EXPLAINN_STAMP
@@ -198,45 +196,6 @@ extern __device__ unsigned long long g_stamps[];
 // Pattern: issue all loads into an array, KEEP() each element in a second loop, then compute.
 #define KEEP(x) asm volatile("" : "+v"(x))
 
-// Copy `rows` rows of a [rows][Bs] u32 array (this lane's column b) into an LDS tile [rows][64].
-// Loads are issued eight at a time before any store: a plain `for (w) tile[w] = src[w]` with a
-// runtime trip count compiles to one exposed memory round trip per row (7-8 us for 27 rows).
-__device__ __forceinline__ void stage_column(uint32_t* __restrict__ tile_lane,
-                                             const uint32_t* __restrict__ src_b, int rows, int Bs) {
-    for (int w0 = 0; w0 < rows; w0 += 8) {
-        uint32_t t[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) t[i] = (w0 + i < rows) ? src_b[(size_t)(w0 + i) * Bs] : 0u;
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (w0 + i < rows) tile_lane[(w0 + i) * 64] = t[i];
-    }
-}
-
-// Two column tiles at once (the packed codes and the N mask of one chunk), EVERY load of both issued
-// before the first store: one exposed round trip instead of one per batch of eight.  R1/R2 are the
-// compile-time tile heights, rows1/rows2 (<= R1/R2) what the sequence still has.
-template <int R1, int R2>
-__device__ __forceinline__ void stage_columns2(uint32_t* __restrict__ t1, const uint32_t* __restrict__ s1,
-                                               int rows1, uint32_t* __restrict__ t2,
-                                               const uint32_t* __restrict__ s2, int rows2, int Bs) {
-    uint32_t a[R1], b[R2];
-#pragma unroll
-    for (int i = 0; i < R1; ++i) a[i] = s1[(size_t)min(i, rows1 - 1) * Bs];
-#pragma unroll
-    for (int i = 0; i < R2; ++i) b[i] = s2[(size_t)min(i, rows2 - 1) * Bs];
-#pragma unroll
-    for (int i = 0; i < R1; ++i) KEEP(a[i]);
-#pragma unroll
-    for (int i = 0; i < R2; ++i) KEEP(b[i]);
-#pragma unroll
-    for (int i = 0; i < R1; ++i)
-        if (i < rows1) t1[i * 64] = a[i];
-#pragma unroll
-    for (int i = 0; i < R2; ++i)
-        if (i < rows2) t2[i * 64] = b[i];
-}
-
 // The filter bank as a GEMM (convpool.hip) on v_mfma_f32_32x32x16_bf16: k-steps of 16 (4 taps x 4
 // bases), 32-unit tiles, two tiles per wave while their fragments and three operand buffers fit
 __host__ __device__ inline int conv_ksteps(int k) { return (k + 3) / 4; }
@@ -246,12 +205,12 @@ __host__ __device__ inline int conv_tiles_padded(int U, int k) {
     return (((U + 31) / 32 + ut - 1) / ut) * ut;
 }
 
-// The filter bank's lookup tables for unit u (all threads of the block call it): Wt (per-tap table,
-// unit-quad interleaved, entry 4 = N = zero) and lut (dinucleotide sums, unit-pair interleaved)
-// from the current filters.  wsh: 4*MAX_K floats of LDS.
+// The filter bank's tables for unit u (all threads of the block call it): Wt (per-tap table,
+// unit-quad interleaved, entry 4 = N = zero: the export and dense kernels), Wf / Wsg (the GEMM's A
+// fragments and pooling signs) from the current filters.  wsh: 4*MAX_K floats of LDS.
 __device__ __forceinline__ void filter_tables_unit(const float* __restrict__ conv_w,
                                                    const float* __restrict__ gamma1,
-                                                   float* __restrict__ Wt, float* __restrict__ lut,
+                                                   float* __restrict__ Wt,
                                                    uint16_t* __restrict__ Wf, uint32_t* __restrict__ Wsg,
                                                    int U, int k, int u, int tid, int nthreads,
                                                    float* wsh) {
@@ -264,17 +223,6 @@ __device__ __forceinline__ void filter_tables_unit(const float* __restrict__ con
     }
     for (int j = tid; j < k; j += nthreads) Wt[((size_t)(u >> 2) * k + j) * 20 + 16 + (u & 3)] = 0.f;
     __syncthreads();
-    // lut[quad][t][c0 c1].{x,y,z,w} = W[u][c0][2t] + W[u][c1][2t+1] for the four units of the quad
-    const int NT = (k + 1) / 2;
-    for (int e = tid; e < NT * 16; e += nthreads) {
-        const int t = e >> 4, code4 = e & 15;
-        float sum = 0.f;
-        for (int i = 0; i < 2; ++i) {
-            const int j = 2 * t + i;
-            if (j < k) sum += wsh[((code4 >> (2 * i)) & 3) * k + j];
-        }
-        lut[(((size_t)(u >> 2) * NT + t) * 16 + code4) * 4 + (u & 3)] = sum;
-    }
     // Wf: the unit's row of the A operand of the filter-bank GEMM (convpool.hip), k = 4 tap + base,
     // as three bf16 pieces whose sum is the fp32 weight exactly.  The pooling direction is folded in:
     // a unit with gamma1 < 0 pools the minimum, so its row is negated (exact) and the kernel takes the

@@ -157,7 +157,6 @@ __global__ __launch_bounds__(64 * PACK_WAVES) void pack_tables_kernel(const floa
                                                           const float* __restrict__ conv_w,
                                                           const float* __restrict__ gamma1,
                                                           float* __restrict__ Wt,
-                                                          float* __restrict__ lut,
                                                           uint16_t* __restrict__ Wf,
                                                           uint32_t* __restrict__ Wsg, int U, int k,
                                                           unsigned long long* __restrict__ bm, int Lp) {
@@ -167,7 +166,7 @@ __global__ __launch_bounds__(64 * PACK_WAVES) void pack_tables_kernel(const floa
         pack_tile<false>(x, nullptr, 0, codesT, pk2, nmask, B, L, Bs, PW, NW, flags, blk % gx, blk / gx,
                          bm, Lp);
     else
-        filter_tables_unit(conv_w, gamma1, Wt, lut, Wf, Wsg, U, k, blk - gx * gy, threadIdx.x, 64 * PACK_WAVES, wsh);
+        filter_tables_unit(conv_w, gamma1, Wt, Wf, Wsg, U, k, blk - gx * gy, threadIdx.x, 64 * PACK_WAVES, wsh);
 }
 
 // Input moments in ONE launch (round 1: 3800 thin ballot waves for the pair counts + a Gram kernel,
@@ -247,7 +246,7 @@ int launch_pack_tables(explainn_ctx* c, const float* x, const explainn_params* p
     c->staged_B = 0;
     hipLaunchKernelGGL(pack_tables_kernel, dim3(gx * gy + c->U4), dim3(64 * PACK_WAVES), 0, s, x, c->codesT,
                        c->pk2, c->nmask, B, c->L, c->Bs, c->PW, c->NW, c->flags, gx, gy, p->conv_w,
-                       p->bn1_w, c->Wt, c->lut, c->Wf, c->Wsg, c->U, c->k, c->bm, c->Lp);
+                       p->bn1_w, c->Wt, c->Wf, c->Wsg, c->U, c->k, c->bm, c->Lp);
     LAUNCH_CHECK();
     return EXPLAINN_OK;
 }

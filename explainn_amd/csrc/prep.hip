@@ -21,16 +21,15 @@ __device__ __forceinline__ double block_sum_128(double v, double* red) {
 }
 
 // prep1 is split in two so that the filter-bank kernel does not wait for the input moments:
-//   prep1_tables  filter taps re-laid for the gather (Wt) + dinucleotide tables (lut)   <- W only
+//   prep1_tables  filter taps re-laid for the export kernels (Wt) and as GEMM fragments (Wf, Wsg)   <- W only
 //   prep1_stats   BatchNorm1 fold (alpha, shift), running statistics, G.w for the backward  <- W, m, G
 __global__ __launch_bounds__(128) void prep1_tables_kernel(const float* __restrict__ conv_w,
                                                            const float* __restrict__ gamma1,
                                                            float* __restrict__ Wt,
-                                                           float* __restrict__ lut,
                                                            uint16_t* __restrict__ Wf,
                                                            uint32_t* __restrict__ Wsg, int U, int k) {
     __shared__ float wsh[4 * MAX_K];
-    filter_tables_unit(conv_w, gamma1, Wt, lut, Wf, Wsg, U, k, blockIdx.x, threadIdx.x, 128, wsh);
+    filter_tables_unit(conv_w, gamma1, Wt, Wf, Wsg, U, k, blockIdx.x, threadIdx.x, 128, wsh);
 }
 
 template <bool TRAIN>
@@ -108,7 +107,7 @@ __global__ __launch_bounds__(128) void prep1_stats_kernel(
 
 int launch_prep1_tables(explainn_ctx* c, const explainn_params* p, hipStream_t s) {
     hipLaunchKernelGGL(prep1_tables_kernel, dim3(c->U4), dim3(128), 0, s, p->conv_w, p->bn1_w, c->Wt,
-                       c->lut, c->Wf, c->Wsg, c->U, c->k);
+                       c->Wf, c->Wsg, c->U, c->k);
     LAUNCH_CHECK();
     return EXPLAINN_OK;
 }

@@ -20,6 +20,8 @@ void explainn_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); v
         if ((threadIdx.x & 63) == 0) {                                                            \
             const size_t s_ = ((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * (blockDim.x / 64) + threadIdx.x / 64) * 8; \
             g_stamps[s_ + (i)] = t_;                                                              \
+            if ((i) == 0) g_stamps[s_ + 6] = __builtin_amdgcn_s_memrealtime();                       \
+            if ((i) == 5) g_stamps[s_ + 6] = __builtin_amdgcn_s_memrealtime() - g_stamps[s_ + 6];     \
             if ((i) == 0) g_stamps[s_ + 7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | \
                                              ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); \
         }                                                                                         \
@@ -27,7 +29,7 @@ void explainn_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); v
 #include "../explainn_amd/csrc/convpool.hip"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
-template <int UT> static void run(int parts) {
+template <int UT, bool IDX> static void run(int parts) {
     const int U = 300, k = 19, L = 200, n = 26, B = 1024, Bs = 1088, NW = (L + 31) / 32 + 2, PW = 2 * NW, KS = 5;
     auto dalloc = [](size_t bytes) { void* p; CK(hipMalloc(&p, bytes)); CK(hipMemset(p, 0, bytes)); return p; };
     const int tiles = conv_tiles_padded(U, k);
@@ -46,12 +48,12 @@ template <int UT> static void run(int parts) {
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipMemset(sp, 0, sizeof(unsigned long long) << 20));
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((conv_pool_mm_kernel<5, UT, true>), grid, dim3(64), 0, 0, pk2, nm, Wf, g1, ext, idx, n, Bs, PW, NW, wper);
+        hipLaunchKernelGGL((conv_pool_mm_kernel<5, UT, IDX>), grid, dim3(64), 0, 0, pk2, nm, Wf, g1, ext, idx, n, Bs, PW, NW, wper);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
     }
     std::vector<unsigned long long> h((size_t)waves * 8);
     CK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_stamps), h.size() * 8));
-    printf("UT=%d parts=%d (wper %d): %d waves, event %.1f us\n", UT, parts, wper, waves, ms * 1e3);
+    printf("UT=%d IDX=%d parts=%d (wper %d): %d waves, event %.1f us\n", UT, (int)IDX, parts, wper, waves, ms * 1e3);
     unsigned long long tmin = ~0ull, tmax = 0;
     for (int w = 0; w < waves; ++w) { if (h[w * 8]) tmin = std::min(tmin, h[w * 8]); tmax = std::max(tmax, h[w * 8 + 5]); }
     printf("  kernel span (first stamp 0 -> last stamp 5): %.0f cyc\n", (double)(tmax - tmin));
@@ -61,6 +63,12 @@ template <int UT> static void run(int parts) {
         for (int w = 0; w < waves; ++w) if (h[w * 8 + p] && h[w * 8 + p - 1]) d.push_back((double)(h[w * 8 + p] - h[w * 8 + p - 1]));
         std::sort(d.begin(), d.end());
         if (!d.empty()) printf("  %-14s p10 %.0f p50 %.0f p90 %.0f max %.0f\n", ph[p - 1], d[d.size() / 10], d[d.size() / 2], d[d.size() * 9 / 10], d.back());
+    }
+    {
+        std::vector<double> mhz;
+        for (int w = 0; w < waves; ++w) if (h[w * 8 + 6] && h[w * 8 + 5] > h[w * 8]) mhz.push_back(100.0 * (double)(h[w * 8 + 5] - h[w * 8]) / (double)h[w * 8 + 6]);
+        std::sort(mhz.begin(), mhz.end());
+        if (!mhz.empty()) printf("  shader clock over the wave's life: p10 %.0f p50 %.0f p90 %.0f MHz\n", mhz[mhz.size() / 10], mhz[mhz.size() / 2], mhz[mhz.size() * 9 / 10]);
     }
     std::map<unsigned, int> simd; std::vector<double> skew, tot;
     for (int w = 0; w < waves; ++w) {
@@ -75,6 +83,6 @@ template <int UT> static void run(int parts) {
 }
 int main() {
     setvbuf(stdout, nullptr, _IOLBF, 0);
-    run<2>(6); run<2>(3);
+    run<2, true>(6); run<2, false>(6); run<2, true>(3); run<2, false>(3);
     return 0;
 }

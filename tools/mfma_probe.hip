@@ -51,7 +51,10 @@ __global__ __launch_bounds__(256, 1) void probe(Rec* rec, float* sink, int reps)
             VALU(NV);
             if (V == 8 || V == 11) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(g) : "a"(c2[k & 15]));
             if (V == 10) asm volatile("v_max_f32 %0, %1, %0" : "+v"(g) : "v"(c2[k & 15]));
-            if (V >= 12) {
+            if (V == 17) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c0) : "a"(a), "a"(b));
+            if (V == 18) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c0) : "a"(a), "v"(b));
+            if (V == 19) { if (k & 1) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c1) : "a"(a), "a"(b)); else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c0) : "a"(a), "a"(b)); }
+            if (V >= 12 && V <= 16) {
                 // chain + the update pattern of conv_pool_mm: compares into SGPR pairs, selects from them
                 asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c0) : "v"(a), "v"(b));
                 if (V == 12 || V == 14 || V == 15 || V == 16) {
@@ -129,5 +132,8 @@ int main() {
     run<14>("32x32x16 1 chain + 2 x update + ds_read_b128 every 3rd", drec, sink);
     run<15>("32x32x16 1 chain + 2 x update + global_store every 3rd", drec, sink);
     run<16>("32x32x16 1 chain + 2 x update + 4 int ops", drec, sink);
+    run<17>("32x32x16 1 chain, VGPR acc, A and B in AccVGPRs", drec, sink);
+    run<18>("32x32x16 1 chain, VGPR acc, A in AccVGPRs, B in VGPRs", drec, sink);
+    run<19>("32x32x16 2 chains, VGPR acc, A and B in AccVGPRs", drec, sink);
     return 0;
 }

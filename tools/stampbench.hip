@@ -145,20 +145,23 @@ int main() {
         uint32_t* pk2 = (uint32_t*)dalloc((size_t)PW * Bs * 4); uint32_t* nmask = (uint32_t*)dalloc((size_t)NW * Bs * 4);
         std::vector<uint32_t> hp((size_t)PW * Bs); for (auto& v : hp) v = (uint32_t)rand() * 65537u;
         CK(hipMemcpy(pk2, hp.data(), hp.size() * 4, hipMemcpyHostToDevice));
-        float* lut = (float*)dalloc((size_t)(U4 / 2) * NT * 32 * 4); float* Wt = (float*)dalloc((size_t)(U4 / 4) * k * 20 * 4);
+        // (the filter bank has its own harness with placement and clock: tools/cpm_stamp.hip; here its
+        // five phases only.  ext of this program has U rows: the kernel gets its own padded arrays)
+        const int tiles = conv_tiles_padded(U, k), KS = conv_ksteps(k);
+        cu32x4* Wf = (cu32x4*)dalloc((size_t)tiles * KS * 3 * 1024); cu32x4* Wsg = (cu32x4*)dalloc((size_t)tiles * 32 * 4);
+        float* extp = (float*)dalloc((size_t)32 * tiles * n * Bs * 4); uint8_t* idxp = (uint8_t*)dalloc((size_t)32 * tiles * n * Bs);
         uint8_t* idx = (uint8_t*)dalloc((size_t)U * n * Bs);
         float* Dspp = (float*)dalloc((size_t)U * (Bs / 16) * 76 * 4);   // (partial stride Bs/16: common.h)
         float* fc1_w = (float*)dalloc((size_t)U * 100 * n * 4); float* VC = (float*)dalloc((size_t)U * 100 * NS * 4);
         double* qbar = (double*)dalloc((size_t)U * NS * 8); float* A2 = (float*)dalloc((size_t)U * 100 * NS * 4);
         float* sig2 = (float*)dalloc(U * 100 * 4); std::vector<float> ones(U * 100, 1.f); CK(hipMemcpy(sig2, ones.data(), U * 100 * 4, hipMemcpyHostToDevice));
         float* md = (float*)dalloc((size_t)U * 100 * n * 4 + 4096);
-        size_t cps = (size_t)(NT * 16 + k * 5) * 16 + (size_t)(8 + 5) * 64 * 4;   // 8-window code tiles (convpool.hip: conv_pool_lds)
         for (int rep = 0; rep < 2; ++rep) {
             clear_stamps();
             CK(hipEventRecord(e0));
-            hipLaunchKernelGGL((conv_pool_kernel<19, 8, true>), dim3(16 * 4, U4 / 4), dim3(64), cps, 0, pk2, nmask, (const float4*)lut, Wt, alpha, U, ext, idx, n, Bs, PW, NW, 4);
+            hipLaunchKernelGGL((conv_pool_mm_kernel<5, 2, true>), dim3(B / 32, tiles / 2, 6), dim3(64), 0, 0, pk2, nmask, Wf, Wsg, extp, idxp, n, Bs, PW, NW, 5);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
-            if (rep) report("conv_pool", 16 * 4 * (U4 / 4), 3, ms);
+            if (rep) report("conv_pool", (B / 32) * (tiles / 2) * 6, 6, ms);
             {   // the matrix-core filter gradient: (32-sequence block, 16-unit tile, window half), two waves
                 static unsigned long long* bmask = nullptr; static float* Dmm = nullptr;
                 const int Lp = ((NW * 32 + 63) / 64) * 64, NT64 = (B + 63) / 64;
