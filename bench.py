@@ -47,12 +47,18 @@ MFMA_F32_PEAK_TFLOPS = 157.3      # same guide: fp32 MFMA = fp32 vector rate
 LDS_PEAK_GBPS = 150000.0          # ds_read_b64/b128 aggregate
 CLOCK_HZ, SIMDS = 2.4e9, 1024
 MFMA_BF16_16x16x32_CLK = 16       # same guide: v_mfma_f32_16x16x32_bf16, cycles per SIMD
+MFMA_BF16_32x32x16_CLK = 32       # v_mfma_f32_32x32x16_bf16 (tools/mfma_probe.hip: 32.0 back to back, 1 or 2 chains)
+# tools/mfma_probe.hip, every SIMD issuing bf16 MFMAs back to back: the shader clock settles at
+# 1.7-1.9 GHz (2.1 with constant operands), not the nominal 2.4 the roofs below are priced at --
+# a kernel that keeps the matrix pipe busy is power-limited before it is issue-limited.
+MFMA_SUSTAINED_CLOCK_GHZ = (1.7, 2.1)
 # Measured here (tools/issue_rate.hip -> profiles/r03_issue_rate.txt), every SIMD of the chip holding
 # 4 waves: shader cycles one SIMD needs per wave-instruction.  Round 2 priced every vector
 # instruction at 4; the guide's 2-cycle figure holds for v_fma_f32 / v_xor_b32 only.
 ISSUE_CLK_PER_INST = {"v_fma_f32, v_xor_b32": 2.4, "other VALU (shifts, bfe, perm, and_or, add3, max, mul_u24, packed fp32)": 4.2,
                       "v_cmp + v_cndmask pair (per instruction)": 3.3, "v_exp_f32": 8.1,
-                      "ds_read_b128": 16.4, "conv_pool instruction mix": 3.9}
+                      "ds_read_b128": 16.4, "vector instruction behind an MFMA (tools/mfma_probe.hip)": 5.0,
+                      "global/buffer store behind an MFMA": 30.0}
 
 
 def launcher_command(argv, gpus, port=None, python=None):
@@ -217,11 +223,15 @@ def kernel_model(w, B):
         "fc_fwd": ("mfma_f32", 2.0 * 100 * n * B * U),
         "passA": ("mfma_f32", 2.0 * 100 * n * B * U),
         "passB": ("mfma_f32", 2.0 * (100 + n) * n * B * U),
-        # LDS bytes the gather reads: one 8-byte dinucleotide row per (sequence, unit pair, position, tap pair)
-        "conv_pool": ("lds", 8.0 * nt * Lo * B * U / 2),
+        # the filter bank as a GEMM on the bf16 matrix core (csrc/convpool.hip): 3 exact pieces x
+        # ceil(k/4) k-steps of v_mfma_f32_32x32x16_bf16 per (32 sequences, 32 units, position); the
+        # unit tiles are padded to whole groups of two (k <= 20)
+        "conv_pool": ("mfma_bf16", 3.0 * ((K + 3) // 4) * ((B + 31) // 32) * (2 * ((U + 63) // 64)) * n * 7,
+                      MFMA_BF16_32x32x16_CLK),
         # the filter gradient as a GEMM on the bf16 matrix core (csrc/bwd.hip): 3 exact pieces x
         # ceil(k/4) column tiles per (32 sequences, 16 units, window, position)
-        "conv_bwd": ("mfma_bf16", 3.0 * ((K + 3) // 4) * ((B + 31) // 32) * ((U + 15) // 16) * n * 7),
+        "conv_bwd": ("mfma_bf16", 3.0 * ((K + 3) // 4) * ((B + 31) // 32) * ((U + 15) // 16) * n * 7,
+                     MFMA_BF16_16x16x32_CLK),
     }
 
 
@@ -392,13 +402,13 @@ def main():
             for name, us in sorted(stage_us.items(), key=lambda kv: -kv[1]):
                 ent = {"us": us}
                 if name in model_k:
-                    kind, work = model_k[name]
+                    kind, work = model_k[name][:2]
                     if kind == "mfma_f32":
                         ent.update(bound="mfma_f32", unpadded_gflop=round(work / 1e9, 3),
                                    mfma_frac=round(work / (us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4))
                     elif kind == "mfma_bf16":
                         # matrix-pipe time of the kernel's own MFMAs at the nominal clock / its duration
-                        roof_us = work * MFMA_BF16_16x16x32_CLK / SIMDS / CLOCK_HZ * 1e6
+                        roof_us = work * model_k[name][2] / SIMDS / CLOCK_HZ * 1e6
                         ent.update(bound="mfma_bf16", mfma_instructions=int(work),
                                    mfma_roof_us=round(roof_us, 2), mfma_frac=round(roof_us / us, 4))
                     else:
@@ -454,6 +464,9 @@ def main():
                          # ~600-900 FLOP/B: no kernel is HBM-bound on algorithmic bytes)
                          "dominant_kernel": dominant,
                          "issue_clk_per_inst": ISSUE_CLK_PER_INST,
+                         "clock_note": "per-kernel roofs are priced at %.1f GHz; with the matrix pipe saturated "
+                                       "the shader clock measured here is %.1f-%.1f GHz (tools/mfma_probe.hip)"
+                                       % (CLOCK_HZ / 1e9, MFMA_SUSTAINED_CLOCK_GHZ[0], MFMA_SUSTAINED_CLOCK_GHZ[1]),
                          "kernels": kernels,
                          "kernel_sum_us": round(sum(stage_us.values()), 1) if stage_us else None},
         }

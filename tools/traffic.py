@@ -20,7 +20,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STAGE = {"pack_tables_kernel": "pack_tables", "moments_kernel": "moments", "prep1_stats_kernel": "prep1_stats",
-         "conv_pool_kernel": "conv_pool", "qmom_kernel": "qmom", "qmom_big_kernel": "qmom",
+         "conv_pool_mm_kernel": "conv_pool", "qmom_kernel": "qmom", "qmom_big_kernel": "qmom",
          "prep2_kernel": "prep2", "fc_fwd_kernel": "fc_fwd", "fc_fwd_bf_kernel": "fc_fwd",
          "head_fwd_train_kernel": "head_fwd", "logits_kernel": "head_fwd", "logits_bn_kernel": "head_fwd", "loss_kernel": "loss", "head_bwd_kernel": "head_bwd",
          "passA_kernel": "passA", "mid_fused_kernel": "mid", "mid_big_kernel": "mid",
