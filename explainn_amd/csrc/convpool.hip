@@ -315,10 +315,17 @@ __global__ __launch_bounds__(64, (UT == 1 && KS <= 5) ? 2 : 1) void conv_pool_mm
     A.tbase = (uint32_t)(size_t)(const lds_char*)oh;
     A.row1 = (uint32_t)(n * Bs); A.row5 = 5u * A.row1;
     {   // descriptors of the group's own 32 UT rows: offsets stay far below 2^31 at any model size
+        // (made wave-uniform by hand: a descriptor the compiler cannot prove uniform gets a
+        // readfirstlane waterfall loop around every store -- seen in the stamped build of this kernel)
         const size_t row0 = (size_t)32 * A.t0 * n * Bs;
-        const int span = 32 * UT * n * Bs;
-        A.rext = __builtin_amdgcn_make_buffer_rsrc(ext + row0, 0, 4 * span, 0x00020000);
-        A.ridx = __builtin_amdgcn_make_buffer_rsrc(idx + row0, 0, span, 0x00020000);
+        const int span = __builtin_amdgcn_readfirstlane(32 * UT * n * Bs);
+        auto uniform = [](auto* q) {
+            const unsigned long long v = reinterpret_cast<unsigned long long>(q);
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+            return reinterpret_cast<decltype(q)>(((unsigned long long)hi << 32) | lo);
+        };
+        A.rext = __builtin_amdgcn_make_buffer_rsrc(uniform(ext + row0), 0, 4 * span, 0x00020000);
+        A.ridx = __builtin_amdgcn_make_buffer_rsrc(uniform(idx + row0), 0, span, 0x00020000);
     }
     const int wbeg = blockIdx.z * wper, wend = min(n, wbeg + wper);
     if (wbeg >= wend) return;

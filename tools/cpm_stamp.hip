@@ -45,7 +45,7 @@ template <int UT, bool IDX> static void run(int parts) {
     const int waves = grid.x * grid.y * grid.z;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); float ms = 0;
     void* sp = nullptr; CK(hipGetSymbolAddress(&sp, HIP_SYMBOL(g_stamps)));
-    for (int rep = 0; rep < 3; ++rep) {
+    for (int rep = 0; rep < 30; ++rep) {
         CK(hipMemset(sp, 0, sizeof(unsigned long long) << 20));
         CK(hipEventRecord(e0));
         hipLaunchKernelGGL((conv_pool_mm_kernel<5, UT, IDX>), grid, dim3(64), 0, 0, pk2, nm, Wf, g1, ext, idx, n, Bs, PW, NW, wper);
