@@ -15,8 +15,8 @@ for B in (100, 1024, 4096):
     for name, inp in (("one-hot", x), ("codes", codes), ("codes rc", BaseCodes(codes, True))):
         # the folded tables are reused across calls only inside an eval_cache() scope (as predict() does)
         with torch.no_grad(), m.eval_cache():
-            for _ in range(10): m(inp)
-            torch.cuda.synchronize(); t0 = time.perf_counter(); K = 200
+            for _ in range(100): m(inp)          # (long enough for the clock to settle after the idle gap)
+            torch.cuda.synchronize(); t0 = time.perf_counter(); K = 1000
             for _ in range(K): m(inp)
             torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
         print("eval B=%-5d %-9s %.3f ms/batch  %.2f M seq/s" % (B, name, dt * 1e3, B / dt / 1e6), flush=True)
