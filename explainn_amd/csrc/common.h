@@ -305,6 +305,13 @@ static inline int nq_bucket(int n) {
         if (b[i] >= n) return b[i];
     return 0;
 }
+// the bucket below NQ (n > nq_lower(NQ) for every n that dispatches to NQ)
+__host__ __device__ constexpr int nq_lower(int NQ) {
+    constexpr int b[] = {0, 4, 8, 12, 16, 20, 24, 26, 28, 32, 40, 48, 56, 64, 72, 84, 96, 112, 128, 140, 160};
+    int lo = 0;
+    for (int i = 1; i < 21; ++i) if (b[i] == NQ) lo = b[i - 1];
+    return lo;
+}
 // ---- tiling of the FC kernels (fc.hip) on v_mfma_f32_16x16x4_f32 ----
 #define FC_MT 7                                          // 16-channel tiles covering the 100 hidden channels
 __host__ __device__ constexpr int fc_nk4(int NQ) { return (NQ + 3) / 4; }      // k-steps over pooled positions

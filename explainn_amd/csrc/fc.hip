@@ -697,10 +697,15 @@ __global__ __launch_bounds__(64 * PA_WAVES, pa_wgt(NQ) <= 2 ? 3 : 2) void passA_
         // one scalar base + a 32-bit byte offset per row (global_load ... saddr): per-row 64-bit
         // vector addresses cost 2 x ROWS registers
         const char* __restrict__ eb = reinterpret_cast<const char*>(eu);
-        const uint32_t boff = (uint32_t)bc * 4u, rstride = (uint32_t)Bs * 4u;
+        // (the row stride sits in a VGPR the compiler cannot see through: with a visible uniform
+        // stride it hoists the 32 row offsets out of the loop -- as SGPRs spilled to lanes, or as
+        // 64-bit vector addresses spilled to scratch, depending on the rest of the loop)
+        const uint32_t boff = (uint32_t)bc * 4u;
+        uint32_t rstride = (uint32_t)Bs * 4u;
+        asm volatile("" : "+v"(rstride));
 #pragma unroll
         for (int i = 0; i < ROWS; ++i)
-            rq[i] = *reinterpret_cast<const float*>(eb + (boff + (uint32_t)min(w0 + i, n - 1) * rstride));
+            rq[i] = *reinterpret_cast<const float*>(eb + (__umul24(rstride, (uint32_t)min(w0 + i, n - 1)) + boff));
         rdz = dzu[bc];
     };
     STAMP(0);
@@ -716,8 +721,14 @@ __global__ __launch_bounds__(64 * PA_WAVES, pa_wgt(NQ) <= 2 ? 3 : 2) void passA_
             const float dzv = (b0 + lane < bend) ? rdz : 0.f;
 #pragma unroll
             for (int i = 0; i < ROWS; ++i) {
+                // (n lies in (NQLO, NQ], the bucket this kernel is instantiated for: with one group
+                // of rows only the rows of that interval -- and row NQLO + 1 = a possible n -- need a
+                // run-time choice; as nested selects on every row this was two scalar branches per
+                // row, 61 per 64 sequences)
                 const int w = w0 + i;
-                rq[i] = w < n ? dzv * qval(a1, rq[i], sh1) : (w == n ? dzv : 0.f);
+                if (pa_ng(NQ) == 1 && i <= nq_lower(NQ)) rq[i] = dzv * qval(a1, rq[i], sh1);
+                else if (pa_ng(NQ) == 1 && i > NQ) rq[i] = 0.f;
+                else rq[i] = w < n ? dzv * qval(a1, rq[i], sh1) : (w == n ? dzv : 0.f);
             }
         }
         // three bf16 pieces of every X value into the LDS image (the store takes the upper half of
@@ -756,12 +767,17 @@ __global__ __launch_bounds__(64 * PA_WAVES, pa_wgt(NQ) <= 2 ? 3 : 2) void passA_
                     const int t = 2 * tp + th;
                     if (t >= FC_MT) break;
                     // A[row r = 16t + c][k = sequence 8g + i]: bit 16th + c of word i -> bf16 1.0 / 0.0
+                    // (as bit | bit << 16 times 0x3f80 in ONE 24-bit multiply: written as masks and-ed
+                    // with the constants, the compiler turned every bit into test + compare + select
+                    // behind a branch -- 457 vector instructions, 119 wait states and 61 branches per
+                    // 64 sequences for what is 224 instructions)
                     u32x4 av;
+                    const uint32_t sh = (uint32_t)(16 * th + c);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const int m0 = __builtin_amdgcn_sbfe(wd[2 * i] >> c, 16 * th, 1);       // 0 / -1
-                        const int m1 = __builtin_amdgcn_sbfe(wd[2 * i + 1] >> c, 16 * th, 1);
-                        av[i] = ((uint32_t)m0 & 0x00003f80u) | ((uint32_t)m1 & 0x3f800000u);
+                        const uint32_t two = __builtin_amdgcn_ubfe(wd[2 * i], sh, 1u) |
+                                             (__builtin_amdgcn_ubfe(wd[2 * i + 1], sh, 1u) << 16);
+                        av[i] = __umul24(two, 0x3f80u);
                     }
                     const bf16x8 afr = __builtin_bit_cast(bf16x8, av);
 #pragma unroll
