@@ -161,11 +161,22 @@ __global__ __launch_bounds__(64) void qmom_kernel(
     const float a1 = alpha[u], sh1 = shift[u];
     const float* __restrict__ eu = ext + (size_t)u * n * Bs;
     // shift = q of sequence 0 (for conditioning; any constant per row would do)
+    // (n lies in (NQLO, NQ]: rows up to NQLO always exist, rows from NQ on never do, only the rows
+    // between need a run-time test -- as a test on every row the compiler made two branches per row;
+    // and the row stride sits in a VGPR it cannot see through, or it hoists 32 row pointers out of
+    // the loop into 64 SGPRs, spills them to lanes and reads each back with wait states in front
+    // of its load)
+    constexpr int NQLO = nq_lower(NQ);
+    uint32_t rstride = (uint32_t)Bs * 4u;
+    asm volatile("" : "+v"(rstride));
+    const char* __restrict__ eb = reinterpret_cast<const char*>(eu);
     float s0[ROWS];
 #pragma unroll
-    for (int i = 0; i < ROWS; ++i) s0[i] = eu[min(i, n - 1) * Bs];
+    for (int i = 0; i < ROWS; ++i)
+        s0[i] = i < NQ ? *reinterpret_cast<const float*>(eb + __umul24(rstride, (uint32_t)min(i, n - 1))) : 0.f;
 #pragma unroll
-    for (int i = 0; i < ROWS; ++i) s0[i] = i < n ? qval(a1, s0[i], sh1) : 0.f;
+    for (int i = 0; i < ROWS; ++i)
+        s0[i] = i <= NQLO ? qval(a1, s0[i], sh1) : (i >= NQ ? 0.f : (i < n ? qval(a1, s0[i], sh1) : 0.f));
     if (ch == 0 && lane == 0) {
 #pragma unroll
         for (int i = 0; i < ROWS; ++i)
@@ -182,12 +193,18 @@ __global__ __launch_bounds__(64) void qmom_kernel(
         const int b = b0 + lane;
         const bool live = b < bend;
         const int bcl = live ? b : bbeg;
+        const uint32_t boff = (uint32_t)bcl * 4u;
 #pragma unroll
-        for (int i = 0; i < ROWS; ++i) rq[i] = eu[min(i, n - 1) * Bs + bcl];
+        for (int i = 0; i < ROWS; ++i)
+            rq[i] = i < NQ ? *reinterpret_cast<const float*>(eb + (__umul24(rstride, (uint32_t)min(i, n - 1)) + boff)) : 0.f;
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) KEEP(rq[i]);
 #pragma unroll
-        for (int i = 0; i < ROWS; ++i) rq[i] = (live && i < n) ? qval(a1, rq[i], sh1) - s0[i] : 0.f;
+        for (int i = 0; i < ROWS; ++i) {
+            if (i <= NQLO) rq[i] = live ? qval(a1, rq[i], sh1) - s0[i] : 0.f;
+            else if (i >= NQ) rq[i] = 0.f;
+            else rq[i] = (live && i < n) ? qval(a1, rq[i], sh1) - s0[i] : 0.f;
+        }
     };
     STAMP(0);
     if (bbeg < bend) fetch(bbeg);
