@@ -860,7 +860,7 @@ int launch_passA(explainn_ctx* c, int B, const pa_head_args* head, hipStream_t s
 // registers themselves.
 // ---------------------------------------------------------------------------------------------
 template <int NQ>
-__global__ __launch_bounds__(256) void passB_kernel(
+__global__ __launch_bounds__(256, 2) void passB_kernel(
     const float* __restrict__ ext, const float* __restrict__ alpha,
     const float* __restrict__ shift, const float* __restrict__ dz, const uint4* __restrict__ bits,
     const float* __restrict__ Ttf, const float* __restrict__ Mff, const float* __restrict__ k0p,

@@ -17,7 +17,7 @@ typedef float f32x16h __attribute__((ext_vector_type(16)));
 enum { EPI_PLAIN = 0, EPI_BIAS = 1, EPI_GW = 2 };
 
 template <bool A_KC, bool B_KC, int EPI>
-__global__ __launch_bounds__(256) void gemm32_kernel(const float* __restrict__ A, int lda,
+__global__ __launch_bounds__(256, 2) void gemm32_kernel(const float* __restrict__ A, int lda,
                                                      const float* __restrict__ Bm, int ldb,
                                                      float* __restrict__ D, int ldd, int M, int N,
                                                      int K, const float* __restrict__ bias,

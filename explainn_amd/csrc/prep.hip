@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64) void qmom_kernel(
 // p mod 4.  (One wave per chunk doing all pairs needed 15 accumulator tiles = 240 VGPRs and a 36 KB
 // tile per WAVE: one wave per SIMD, 236 us at C4 against a 68 us MFMA roof.)
 template <int NQ>
-__global__ __launch_bounds__(256) void qmom_big_kernel(
+__global__ __launch_bounds__(256, 2) void qmom_big_kernel(
     const float* __restrict__ ext, const float* __restrict__ alpha,
     const float* __restrict__ shift, float* __restrict__ qs0, float* __restrict__ S1p,
     float* __restrict__ S2p, int n, int Bs, int B, int QCH) {
