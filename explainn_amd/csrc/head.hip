@@ -99,6 +99,21 @@ __device__ __forceinline__ double block_sum_256(double v, double* red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// three sums behind ONE pair of barriers (head_bwd: the two BatchNorm3 sums and the combiner-weight
+// gradient of the register path used to take three round trips)
+__device__ __forceinline__ void block_sum3_256(double& a, double& b, double& c, double* red12) {
+    a = wave_sum_d(a); b = wave_sum_d(b); c = wave_sum_d(c);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        red12[w] = a; red12[4 + w] = b; red12[8 + w] = c;
+    }
+    __syncthreads();
+    a = (red12[0] + red12[1]) + (red12[2] + red12[3]);
+    b = (red12[4] + red12[5]) + (red12[6] + red12[7]);
+    c = (red12[8] + red12[9]) + (red12[10] + red12[11]);
+}
+
 // one block per unit: batch statistics of z, then zhat / o
 __global__ __launch_bounds__(256) void head_fwd_train_kernel(
     const float* __restrict__ z, const float* __restrict__ c2, const float* __restrict__ g3,
@@ -407,6 +422,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
     float* __restrict__ gbf, float* __restrict__ gg3, float* __restrict__ gb3,
     float* __restrict__ gc2, int U, int T, int Bs, int B) {
     __shared__ double red[4];
+    __shared__ double red3[12];
     const int u = blockIdx.x, tid = threadIdx.x;
     const float* ou = o + (size_t)u * Bs;
     const float* zh = zhat + (size_t)u * Bs;
@@ -471,8 +487,13 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
             s2 = fma((double)d3, (double)zh[b], s2);
         }
     }
-    const double S1 = block_sum_256(s1, red);
-    const double S2 = block_sum_256(s2, red);
+    double S1 = s1, S2 = s2, G0 = gw[0];
+    if (inreg) {
+        block_sum3_256(S1, S2, G0, red3);          // (inreg is block-uniform: so are the barriers)
+    } else {
+        S1 = block_sum_256(s1, red);
+        S2 = block_sum_256(s2, red);
+    }
     const float m1 = (float)(S1 / (double)B), m2 = (float)(S2 / (double)B);
     const float sc = g3[u] / sig3[u];
     if (inreg) {
@@ -488,7 +509,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             if (t >= T) continue;                      // T is block-uniform: the barriers inside stay uniform
-            const double tot = block_sum_256(gw[t], red);
+            const double tot = t == 0 ? G0 : block_sum_256(gw[t], red);
             if (tid == 0) gWf[(size_t)t * U + u] = (float)tot;
             if (u == 0) {
                 const double ct = block_sum_256(gb[t], red);
