@@ -47,34 +47,75 @@ __global__ __launch_bounds__(1024) void mid_fused_kernel(
     float* sgl = gsl + FC_H;                 // [100]      12 K of the block's 31 K cycles)
     const int u = blockIdx.x, tid = threadIdx.x;
     STAMP(0);
-    for (int e = tid; e < FC_H * n; e += 1024) {
-        const int r = e / n, w = e % n;
-        const size_t ch = (size_t)u * FC_H + r;
-        V1s[r * ld + w] = fc1_w[ch * n + w];
-        A2s[r * ld + w] = A2[ch * NS + w];
-        VCl[r * ld + w] = VC[ch * NS + w];
+    {
+        // (all the loads of the block's three passes over [100][n] in flight before the first LDS store:
+        // as a loop with a run-time trip count every pass was its own memory round trip)
+        // (three passes per batch: 9 values + 3 LDS addresses, inside the 64 registers that let two
+        // blocks share a CU; n <= 30 is one batch)
+        constexpr int NPASS = 3;
+        for (int e0 = tid; e0 < FC_H * n; e0 += 1024 * NPASS) {
+            float v1[NPASS], a2[NPASS], vc[NPASS];
+            int dst[NPASS];
+#pragma unroll
+            for (int it = 0; it < NPASS; ++it) {
+                const int e = e0 + 1024 * it;
+                const bool on = e < FC_H * n;
+                const int ec = on ? e : 0, r = ec / n, w = ec - r * n;
+                const uint32_t ch = (uint32_t)(u * FC_H + r);
+                dst[it] = on ? r * ld + w : -1;
+                v1[it] = fc1_w[(size_t)ch * n + w];
+                a2[it] = A2[(size_t)ch * NS + w];
+                vc[it] = VC[(size_t)ch * NS + w];
+            }
+#pragma unroll
+            for (int it = 0; it < NPASS; ++it) { KEEP(v1[it]); KEEP(a2[it]); KEEP(vc[it]); }
+#pragma unroll
+            for (int it = 0; it < NPASS; ++it)
+                if (dst[it] >= 0) { V1s[dst[it]] = v1[it]; A2s[dst[it]] = a2[it]; VCl[dst[it]] = vc[it]; }
+        }
     }
     // passA's partial sums are stored w-major (EQp[..][w][r]): r is the fast index here
-    for (int e = tid; e < FC_H * n; e += 1024) {
-        const int w = e / FC_H, r = e % FC_H;
-        double eq = 0;
-        for (int c0 = 0; c0 < ACH; c0 += 8) {         // eight partials in flight, fixed-order sum
-            float pv[8];
+    for (int e0 = tid; e0 < FC_H * n; e0 += 1024 * 3) {
+        // three passes x four partials in flight, fixed-order sums (one round trip at ACH <= 4, n <= 30)
+        double eq[3] = {0, 0, 0};
+        for (int c0 = 0; c0 < ACH; c0 += 4) {
+            float pv[3][4];
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                pv[i] = EQp[(((size_t)u * ACH + min(c0 + i, ACH - 1)) * NS + w) * FC_H + r];
+            for (int it = 0; it < 3; ++it) {
+                const int e = e0 + 1024 * it, ec = e < FC_H * n ? e : 0;
+                const int w = ec / FC_H, r = ec % FC_H;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) KEEP(pv[i]);
+                for (int i = 0; i < 4; ++i)
+                    pv[it][i] = EQp[(((size_t)u * ACH + min(c0 + i, ACH - 1)) * NS + w) * FC_H + r];
+            }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) eq += (c0 + i < ACH) ? (double)pv[i] : 0.0;
+            for (int it = 0; it < 3; ++it)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) KEEP(pv[it][i]);
+#pragma unroll
+            for (int it = 0; it < 3; ++it)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) eq[it] += (c0 + i < ACH) ? (double)pv[it][i] : 0.0;
         }
-        EQl[r * ld + w] = (float)eq;
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int e = e0 + 1024 * it;
+            if (e < FC_H * n) EQl[(e % FC_H) * ld + e / FC_H] = (float)eq[it];
+        }
     }
     double* qbd = reinterpret_cast<double*>((reinterpret_cast<size_t>(sgl + FC_H) + 7) & ~size_t(7));   // [n] doubles
     for (int w = tid; w < n; w += 1024) { const double v = qbar[(size_t)u * NS + w]; qb[w] = (float)v; qbd[w] = v; }
     for (int r = tid; r < FC_H; r += 1024) {
         double s = 0;
-        for (int c = 0; c < ACH; ++c) s += (double)Sep[((size_t)u * ACH + c) * FC_H + r];
+        for (int c0 = 0; c0 < ACH; c0 += 4) {          // four partials in flight (was one round trip each)
+            float pv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pv[i] = Sep[((size_t)u * ACH + min(c0 + i, ACH - 1)) * FC_H + r];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) KEEP(pv[i]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s += (c0 + i < ACH) ? (double)pv[i] : 0.0;
+        }
         se[r] = (float)s;
     }
     __syncthreads();
