@@ -247,6 +247,16 @@ def test_adam_trajectory_golden(golden):
     (4, 19, 61, 2, 600, 0.0),       # few tasks, batch > 512: the per-unit head backward kernel (smaller
                                     # batches run it inside passA)
     (1100, 5, 40, 2, 70, 0.0),      # more units than threads in the combiner block that finishes BatchNorm3
+    # the lower edge of a pooled-length bucket (n = previous bucket + 1): passA and qmom decide at
+    # compile time which rows always / never exist inside the bucket (csrc/common.h: nq_lower)
+    (3, 19, 109, 1, 70, 0.0),       # n = 13 -> bucket 16
+    (3, 19, 165, 1, 70, 0.02),      # n = 21 -> bucket 24
+    (3, 19, 186, 2, 70, 0.0),       # n = 24 = bucket 24's upper edge
+    (3, 19, 193, 1, 70, 0.0),       # n = 25 -> bucket 26 (C2's kernels, one row short)
+    (3, 19, 207, 1, 70, 0.0),       # n = 27 -> bucket 28
+    (3, 19, 249, 1, 70, 0.0),       # n = 33 -> bucket 40 (first size with two row groups in passA)
+    (3, 19, 305, 1, 70, 0.0),       # n = 41 -> bucket 48
+    (2, 19, 529, 1, 70, 0.0),       # n = 73 -> bucket 84: the first n of the large-n kernels
 ])
 def test_train_step_vs_oracle(U, k, L, T, B, nfrac):
     sd = orc.random_state_dict(U, k, L, T, seed=U + L)
