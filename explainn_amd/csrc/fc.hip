@@ -78,6 +78,17 @@ __device__ __forceinline__ void fc_epilogue_tile(const f32x4& acc, int t, int g,
                                                  float& zp, uint32_t (&words)[4]) {
     const float4 v2 = *reinterpret_cast<const float4*>(&v2s[16 * t + 4 * g]);
     const float v2a[4] = {v2.x, v2.y, v2.z, v2.w};
+    if (MODE == 0) {
+        // eval: no bits to keep (the shift-ins are volatile assembly: they stayed in the eval kernel,
+        // 28 per 16 sequences, until this branch), ReLU as a plain max
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float y = acc[j];
+            asm("v_max_f32 %0, 0, %0" : "+v"(y));          // (fmaxf would canonicalise first)
+            zp = fmaf(v2a[j], y, zp);
+        }
+        return;
+    }
     unsigned long long pm[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
