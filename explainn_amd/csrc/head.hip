@@ -228,21 +228,32 @@ __global__ __launch_bounds__(1024) void logits_bn_kernel(
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int b = blockIdx.x * 64 + lane, t = blockIdx.y;
     const bool owner = blockIdx.x == 0 && blockIdx.y == 0;
+    // the first batch of z loads does not depend on the statistics: requested before them, so that
+    // the kernel's two round trips overlap (the combiner weights ride in LDS beside the statistics:
+    // with them in the batch too the kernel spilled at its 128 registers)
+    constexpr int LQ = 20;
+    const float* wr = Wf + (size_t)t * U;
+    float* wl = reinterpret_cast<float*>(st4 + U);      // [U] combiner weights of task t
+    float zq0[LQ];
+#pragma unroll
+    for (int q = 0; q < LQ; ++q)
+        zq0[q] = z[(uint32_t)min(wv + 16 * q, U - 1) * (uint32_t)Bs + (uint32_t)b];
     for (int u = threadIdx.x; u < U; u += 1024) {
         double s1 = 0, s2 = 0;
-        for (int i0 = 0; i0 < nblk; i0 += 8) {           // eight partial pairs in flight per round trip
-            double2 pv[8];
+        for (int i0 = 0; i0 < nblk; i0 += 4) {           // four partial pairs in flight per round trip
+            double2 pv[4];                                // (eight, with the z batch above held, spilled)
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < 4; ++i)
                 pv[i] = *reinterpret_cast<const double2*>(&z12p[((size_t)u * nblk + min(i0 + i, nblk - 1)) * 2]);
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < 4; ++i)
                 if (i0 + i < nblk) { s1 += pv[i].x; s2 += pv[i].y; }
         }
         const double mean = s1 / (double)B;
         const double var = fmax(s2 / (double)B - mean * mean, 0.0);
         const double sg = sqrt(var + BN_EPS_D);
         st4[u] = make_float4((float)mean, (float)(1.0 / sg), g3[u], b3[u]);
+        wl[u] = wr[u];
         if (owner) {
             sig3[u] = (float)sg;
             rm3[u] = (float)((1 - BN_MOM_D) * (double)rm3[u] + BN_MOM_D * (mean + (double)c2[u]));
@@ -251,25 +262,25 @@ __global__ __launch_bounds__(1024) void logits_bn_kernel(
         }
     }
     __syncthreads();
-    const float* wr = Wf + (size_t)t * U;
     const bool store = t == 0 && b < B;
     float acc = 0.f;
     // twenty units (forty loads) in flight per wave: the 300 units of the headline shape are one
     // memory round trip per wave (ten at a time made two dependent ones in a kernel that is nothing
     // but round trips)
-    constexpr int LQ = 20;
     for (int u0 = wv; u0 < U; u0 += 16 * LQ) {
-        float wq[LQ], zq[LQ];
+        float zq[LQ];
+        if (u0 == wv) {
 #pragma unroll
-        for (int q = 0; q < LQ; ++q) {
-            const int u = min(u0 + 16 * q, U - 1);
-            wq[q] = wr[u];
+            for (int q = 0; q < LQ; ++q) zq[q] = zq0[q];
+        } else {
             // (32-bit element offset from the uniform base: a 64-bit address per load took two
             // registers each and spilled)
-            zq[q] = z[(uint32_t)u * (uint32_t)Bs + (uint32_t)b];
+#pragma unroll
+            for (int q = 0; q < LQ; ++q)
+                zq[q] = z[(uint32_t)min(u0 + 16 * q, U - 1) * (uint32_t)Bs + (uint32_t)b];
         }
 #pragma unroll
-        for (int q = 0; q < LQ; ++q) { KEEP(wq[q]); KEEP(zq[q]); }
+        for (int q = 0; q < LQ; ++q) KEEP(zq[q]);
 #pragma unroll
         for (int q = 0; q < LQ; ++q) {
             const int u = u0 + 16 * q;
@@ -281,7 +292,7 @@ __global__ __launch_bounds__(1024) void logits_bn_kernel(
                     const uint32_t off = (uint32_t)u * (uint32_t)Bs + (uint32_t)b;
                     zhat[off] = zh; o[off] = ov;
                 }
-                acc = fmaf(wq[q], ov, acc);
+                acc = fmaf(wl[u], ov, acc);
             }
         }
     }
@@ -306,9 +317,9 @@ __global__ __launch_bounds__(256) void outs_kernel(const float* __restrict__ o,
 
 int launch_head_fwd(explainn_ctx* c, const explainn_params* p, int B, bool train, float* logits,
                     float* outs, hipStream_t s) {
-    if (train && logits && c->T <= HEAD_GEMM_MIN_T && !outs && (size_t)c->U * sizeof(float4) <= 48 * 1024) {
+    if (train && logits && c->T <= HEAD_GEMM_MIN_T && !outs && (size_t)c->U * (sizeof(float4) + sizeof(float)) <= 48 * 1024) {
         hipLaunchKernelGGL(logits_bn_kernel, dim3((B + 63) / 64, c->T), dim3(1024),
-                           (size_t)c->U * sizeof(float4), s, c->z, c->z12p, fc_fwd_blocks(B, c->NQ),
+                           (size_t)c->U * (sizeof(float4) + sizeof(float)), s, c->z, c->z12p, fc_fwd_blocks(B, c->NQ),
                            p->fc2_b, p->bn3_w, p->bn3_b, p->bn3_rm, p->bn3_rv, p->bn3_nbt, c->zhat,
                            c->o, c->sig3, p->final_w, p->final_b, logits, c->U, c->T, c->Bs, B);
         LAUNCH_CHECK();
