@@ -55,22 +55,30 @@ __global__ __launch_bounds__(128) void prep1_stats_kernel(
         }
         return;
     }
-    for (int i = tid; i < K4; i += 128) wsh[i] = (double)conv_w[(size_t)u * K4 + i];
-    // G (K4 x K4 doubles, 46 KB at k = 19) is staged in LDS with every load of a thread in flight at
-    // once: the product below then never waits on global memory (walking G from global was ten
-    // dependent round trips per block, 9-13 us for a kernel with 1.7 MFLOP of work)
+    // everything the block reads is requested up front: the filter, this thread's entry of m, the
+    // unit's BatchNorm parameters (thread 0 uses them at the very end) and G -- K4 x K4 doubles, 46 KB
+    // at k = 19, staged in LDS 48 per thread per pass, so that k <= 19 is ONE memory round trip (16 per
+    // pass were three, with m and the parameters two more behind the barrier; walking G from global
+    // had been ten)
+    const int mi = min(tid, K4 - 1);
+    const float wme = conv_w[(size_t)u * K4 + mi];
+    const double mme = m[mi];
+    const float g1u = g1[u], b1u = b1[u], cbu = conv_b[u], rmu = rm[u], rvu = rv[u];
+    for (int i = tid + 128; i < K4; i += 128) wsh[i] = (double)conv_w[(size_t)u * K4 + i];
     extern __shared__ double Gs[];
     {
         const int n2 = K4 * K4;
-        for (int e0 = tid; e0 < n2; e0 += 128 * 16) {
-            double gv[16];
+        constexpr int GQ = 48;
+        for (int e0 = tid; e0 < n2; e0 += 128 * GQ) {
+            double gv[GQ];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) gv[q] = G[min(e0 + q * 128, n2 - 1)];
+            for (int q = 0; q < GQ; ++q) gv[q] = G[min(e0 + q * 128, n2 - 1)];
 #pragma unroll
-            for (int q = 0; q < 16; ++q)
+            for (int q = 0; q < GQ; ++q)
                 if (e0 + q * 128 < n2) Gs[e0 + q * 128] = gv[q];
         }
     }
+    if (tid < K4) wsh[tid] = (double)wme;
     __syncthreads();
     double mu_p = 0, q_p = 0;
     for (int i = tid; i < K4; i += 128) {
@@ -84,7 +92,7 @@ __global__ __launch_bounds__(128) void prep1_stats_kernel(
         if (c0 < K4) g0 = fma(Gs[c0 * K4 + i], wsh[c0], g0);
         const double gw = g0 + g1s;
         Gw[(size_t)u * K4 + i] = gw;
-        mu_p = fma(wsh[i], m[i], mu_p);
+        mu_p = fma(wsh[i], i == tid ? mme : m[i], mu_p);
         q_p = fma(wsh[i], gw, q_p);
     }
     const double mu = block_sum_128(mu_p, red);
@@ -93,14 +101,14 @@ __global__ __launch_bounds__(128) void prep1_stats_kernel(
         double var = wGw - mu * mu;
         var = var > 0 ? var : 0;
         const double sg = sqrt(var + BN_EPS_D);
-        const double a = (double)g1[u] / sg;
+        const double a = (double)g1u / sg;
         alpha[u] = (float)a;
-        shift[u] = (float)((double)b1[u] - a * mu);
+        shift[u] = (float)((double)b1u - a * mu);
         mug[u] = mu;
         sig1[u] = sg;
         const double N1 = (double)B * (double)Lo;
-        rm[u] = (float)((1 - BN_MOM_D) * (double)rm[u] + BN_MOM_D * ((double)conv_b[u] + mu));
-        rv[u] = (float)((1 - BN_MOM_D) * (double)rv[u] + BN_MOM_D * var * N1 / (N1 - 1));
+        rm[u] = (float)((1 - BN_MOM_D) * (double)rmu + BN_MOM_D * ((double)cbu + mu));
+        rv[u] = (float)((1 - BN_MOM_D) * (double)rvu + BN_MOM_D * var * N1 / (N1 - 1));
         if (u == 0 && nbt) *nbt += 1;
     }
 }
