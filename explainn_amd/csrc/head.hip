@@ -439,6 +439,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
     const float* zh = zhat + (size_t)u * Bs;
     float* dzu = dz + (size_t)u * Bs;
     const float invN = 1.0f / (float)(B * T);
+    const float g3u = g3[u], sig3u = sig3[u];        // (used behind the block sums: requested here)
     double s1 = 0, s2 = 0;
     // small batches and few tasks: d3 and zhat of this thread's sequences stay in registers between
     // the two passes (one batch of loads each instead of a dependent round trip per 256 sequences)
@@ -506,7 +507,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
         S2 = block_sum_256(s2, red);
     }
     const float m1 = (float)(S1 / (double)B), m2 = (float)(S2 / (double)B);
-    const float sc = g3[u] / sig3[u];
+    const float sc = g3u / sig3u;
     if (inreg) {
 #pragma unroll
         for (int i = 0; i < RB; ++i)
