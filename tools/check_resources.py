@@ -32,6 +32,11 @@ C2_STEP = [
 ]
 
 
+# Register cliffs measured in the pipeline: 1024-thread blocks of which TWO must
+# share a CU (300 units on 256 CUs take two rounds otherwise) -- 64 registers, not one more.
+VGPR_CAP = {r"^mid_fused_kernel": 64, r"^prep2_kernel<true>": 64}
+
+
 def demangle(names):
     out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout
     return [re.sub(r"^void ", "", l.replace("(anonymous namespace)::", "").split("(")[0]) for l in out.splitlines()]
@@ -81,6 +86,12 @@ def main():
             print("check_resources: note: %s (%s) uses scratch: %d B/lane, %d sgpr, %d vgpr spilled" % (
                 r["name"], r["file"], r.get("scratch", 0), r.get("sgpr_spill", 0), r.get("vgpr_spill", 0)))
     rc = 0
+    for r in rows:
+        for pat, cap in VGPR_CAP.items():
+            if re.search(pat, r["name"]) and r.get("vgpr", 0) + r.get("agpr", 0) > cap:
+                print("check_resources: ERROR: %s uses %d registers, over its cap of %d (two blocks per CU)"
+                      % (r["name"], r.get("vgpr", 0) + r.get("agpr", 0), cap))
+                rc = 1
     for p in missing:
         print("check_resources: ERROR: no kernel matches the C2-step pattern %r (renamed? update C2_STEP)" % p)
         rc = 1
