@@ -182,6 +182,41 @@ __global__ __launch_bounds__(64) void qmom_kernel(
 #pragma unroll
     for (int i = 0; i < ROWS; ++i)
         s0[i] = i < NQ ? *reinterpret_cast<const float*>(eb + __umul24(rstride, (uint32_t)min(i, n - 1))) : 0.f;
+    f32x4q acc[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) acc[p] = f32x4q{0.f, 0.f, 0.f, 0.f};
+    float s1[NW16];
+#pragma unroll
+    for (int j = 0; j < NW16; ++j) s1[j] = 0.f;
+    // a tile's rows are REQUESTED (issue) one tile ahead and TURNED INTO q - s0 (finish) behind the
+    // MFMAs of the tile in front: as one lambda the transform sat right behind the loads and the
+    // "prefetch" waited on the spot
+    float rq[ROWS];
+    bool rlive = false;
+    auto issue = [&](int b0) {
+        const int b = b0 + lane;
+        rlive = b < bend;
+        const uint32_t boff = (uint32_t)(rlive ? b : bbeg) * 4u;
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i)
+            rq[i] = i < NQ ? *reinterpret_cast<const float*>(eb + (__umul24(rstride, (uint32_t)min(i, n - 1)) + boff)) : 0.f;
+    };
+    auto finish = [&]() {
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) KEEP(rq[i]);
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) {
+            if (i <= NQLO) rq[i] = rlive ? qval(a1, rq[i], sh1) - s0[i] : 0.f;
+            else if (i >= NQ) rq[i] = 0.f;
+            else rq[i] = (rlive && i < n) ? qval(a1, rq[i], sh1) - s0[i] : 0.f;
+        }
+    };
+    STAMP(0);
+    // (the first tile's rows are requested before the shift row is turned into q: one round trip
+    // for both)
+    if (bbeg < bend) issue(bbeg);
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) KEEP(s0[i]);
 #pragma unroll
     for (int i = 0; i < ROWS; ++i)
         s0[i] = i <= NQLO ? qval(a1, s0[i], sh1) : (i >= NQ ? 0.f : (i < n ? qval(a1, s0[i], sh1) : 0.f));
@@ -190,37 +225,14 @@ __global__ __launch_bounds__(64) void qmom_kernel(
         for (int i = 0; i < ROWS; ++i)
             if (i < NS) qs0[(size_t)u * NS + i] = s0[i];
     }
-    f32x4q acc[NP];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) acc[p] = f32x4q{0.f, 0.f, 0.f, 0.f};
-    float s1[NW16];
-#pragma unroll
-    for (int j = 0; j < NW16; ++j) s1[j] = 0.f;
-    float rq[ROWS];
-    auto fetch = [&](int b0) {
-        const int b = b0 + lane;
-        const bool live = b < bend;
-        const int bcl = live ? b : bbeg;
-        const uint32_t boff = (uint32_t)bcl * 4u;
-#pragma unroll
-        for (int i = 0; i < ROWS; ++i)
-            rq[i] = i < NQ ? *reinterpret_cast<const float*>(eb + (__umul24(rstride, (uint32_t)min(i, n - 1)) + boff)) : 0.f;
-#pragma unroll
-        for (int i = 0; i < ROWS; ++i) KEEP(rq[i]);
-#pragma unroll
-        for (int i = 0; i < ROWS; ++i) {
-            if (i <= NQLO) rq[i] = live ? qval(a1, rq[i], sh1) - s0[i] : 0.f;
-            else if (i >= NQ) rq[i] = 0.f;
-            else rq[i] = (live && i < n) ? qval(a1, rq[i], sh1) - s0[i] : 0.f;
-        }
-    };
-    STAMP(0);
-    if (bbeg < bend) fetch(bbeg);
+    if (bbeg < bend) finish();
     for (int b0 = bbeg; b0 < bend; b0 += 64) {
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) tq[i * QS_LD + lane] = rq[i];
         if (b0 == bbeg) STAMP(1);
-        if (b0 + 64 < bend) fetch(b0 + 64);           // in flight during the MFMAs below
+        const bool more = b0 + 64 < bend;
+        if (more) issue(b0 + 64);                       // in flight during the MFMAs below
+        __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
@@ -237,6 +249,8 @@ __global__ __launch_bounds__(64) void qmom_kernel(
                 for (int j2 = j; j2 < NW16; ++j2, ++p)
                     acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], av[j2], acc[p], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) finish();
         __builtin_amdgcn_wave_barrier();
     }
     STAMP(2);
