@@ -257,6 +257,12 @@ def test_adam_trajectory_golden(golden):
     (3, 19, 249, 1, 70, 0.0),       # n = 33 -> bucket 40 (first size with two row groups in passA)
     (3, 19, 305, 1, 70, 0.0),       # n = 41 -> bucket 48
     (2, 19, 529, 1, 70, 0.0),       # n = 73 -> bucket 84: the first n of the large-n kernels
+    # the filter-bank GEMM's edges: one pooling window (a wave's first window is its last), the
+    # widest kernel with one window, unit counts that leave a 32-unit tile / a two-tile group partly empty
+    (3, 19, 25, 1, 9, 0.0),         # n = 1, Lo = 7
+    (2, 32, 38, 1, 7, 0.0),         # k = 32, n = 1
+    (33, 19, 32, 1, 31, 0.0),       # 33 units: tile 1 holds one unit
+    (65, 4, 200, 1, 100, 0.02),     # 65 units: three tiles, the second group half empty; k = 4 is one k-step
 ])
 def test_train_step_vs_oracle(U, k, L, T, B, nfrac):
     sd = orc.random_state_dict(U, k, L, T, seed=U + L)
