@@ -189,12 +189,8 @@ template <int KS, int UT, int I> struct cpm_sched {
     static constexpr int NM = 3 * KS * UT;
     static constexpr int T0 = (UT + 1) / 2;                     // tiles stored at position 0
     static constexpr int NX = I == 6 ? 1 : 0, NG = KS, NE = 16 * UT;
-#ifdef CPM_NO_S
-    static constexpr int NS0 = 0, NS1 = 0;
-#else
     static constexpr int NS0 = I == 0 ? 16 * T0 : 0;            // after the updates
     static constexpr int NS1 = I == 1 ? 16 * (UT - T0) : 0;     // before the updates
-#endif
     // weights in units of ~5 issue cycles (tools/mfma_probe.hip: a vector instruction behind an MFMA
     // ~5, a store ~30): words 12, operand 5, update 3 (assignment 1), a pair of stores + offsets 9
     static constexpr int WX = 12, WG = 5, WE = (I == 1) ? 1 : 3, WS = 9;
@@ -416,7 +412,7 @@ int launch_conv_pool_mm(explainn_ctx* c, const explainn_params* p, int B, bool w
     else hipLaunchKernelGGL((conv_pool_mm_kernel<KSv, UTv, false>), ARGS);
 #define CALLUT(KSv) if (ut == 2) { CALLKS(KSv, 2); } else { CALLKS(KSv, 1); }
     switch (conv_ksteps(c->k)) {
-#ifndef CPM_ONLY5
+#ifndef CPM_ONLY5     /* (development builds: -DCPM_ONLY5 compiles the k = 17..20 forms only) */
         case 1: { CALLUT(1); } break;
         case 2: { CALLUT(2); } break;
         case 3: { CALLUT(3); } break;

@@ -1,5 +1,5 @@
 // Stamp harness for conv_pool_mm alone (C2 shape): per-wave phase cycles and SIMD placement.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DCPM_ONLY5 tools/cpm_stamp.hip -o tools/_bin/cpm_stamp
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/cpm_stamp.hip -o tools/_bin/cpm_stamp
 #define EXPLAINN_STAMP 1
 #include <hip/hip_runtime.h>
 #include <stdio.h>
