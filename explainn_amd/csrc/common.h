@@ -47,7 +47,7 @@ struct explainn_ctx {
     double* m;            // [4k]             mean window indicator
     float* alpha;         // [U4]             BN1 scale   gamma1/sigma1
     float* shift;         // [U4]             BN1 shift   (bias and mean folded in)
-    double* mug;          // [U4]             mean of the raw gather sum
+    double* mug;          // [U4]             mean of the raw conv sum
     double* sig1;         // [U4]
     double* Gw;           // [U4][4k]
     float* Wt;            // [Uq][k][5][4]    filter taps, unit-quad interleaved, code 4 -> 0
@@ -55,7 +55,7 @@ struct explainn_ctx {
                           // order a lane of the filter-bank GEMM holds its 16 rows
     uint16_t* Wf;         // [tiles32 (padded to whole unit groups)][KS][3 pieces][64 lanes][8] bf16: the filters as
                           // A fragments of v_mfma_f32_32x32x16_bf16 (k = 4 tap + base), sign(gamma1) folded in
-    float* ext;           // [U4][n][Bs]      pooled extreme of the raw gather sum
+    float* ext;           // [U4 (padded to 64-unit groups)][n][Bs]  pooled extreme of the raw conv sum
     uint8_t* idx;         // [U4][n][Bs]      argmax offset 0..6 inside the pooling window
     float* qs0;           // [U][NS]          shift for the q moments (q of sequence 0)
     float* qS1p;          // [U][QCH][NS]

@@ -1,6 +1,6 @@
 // Fallback for inputs that are NOT one-hot.  The reference's forward accepts any float tensor
 // (architectures/__init__.py:111 hands x straight to a grouped Conv1d); everything in this library
-// that makes the filter bank fast -- base codes, dinucleotide tables, integer pair counts -- needs
+// that makes the filter bank fast -- base codes, one-hot bit operands, integer pair counts -- needs
 // one-hot columns.  A "soft" input (position-probability matrices, a blend of sequences) therefore
 // takes these four plain kernels for the stages that touch x, and the regular pipeline for
 // everything behind the pooled activations:
