@@ -84,6 +84,7 @@ void carve(explainn_ctx* c, Carver& cv) {
     cv.take(&c->dlogits, (int64_t)c->maxB * c->T);
     cv.take(&c->flags, 64);
     cv.take(&c->dlT, (int64_t)c->T * Bs);
+    cv.take(&c->gWp, c->T > HEAD_GEMM_MIN_T ? (int64_t)head_gw_chunks(c->maxB) * c->T * (c->U + 1) : 0);
     cv.take(&c->lossp, 64);
     cv.take(&c->site_cnt, U4 * Bs);
     cv.take(&c->site_off, U4 * Bs);

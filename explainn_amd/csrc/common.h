@@ -10,6 +10,10 @@
 #define FC_H 100          // hidden width of the per-unit FC (architectures/__init__.py:86)
 #define HEAD_RB 8            // head kernels keep up to HEAD_RB*256 sequences per unit in registers
 #define HEAD_GEMM_MIN_T 8   // more tasks than this: combiner forward/backward as MFMA GEMMs (head.hip)
+// d Wf = dl^T o^T has K = batch and only ceil(T/32) x ceil((U+1)/32) output tiles (20 at C3): the batch is
+// cut into chunks of >= 128 sequences, one workgroup per (tile, chunk), summed per unit in head_bwd
+#define HEAD_GW_MAXCH 32
+__host__ inline int head_gw_chunks(int B) { int c = (B + 127) / 128; return c < 1 ? 1 : (c > HEAD_GW_MAXCH ? HEAD_GW_MAXCH : c); }
 #define POOLW 7           // MaxPool1d(7,7)        (architectures/__init__.py:81)
 #define BN_EPS_D 1e-5     // architectures/__init__.py:79,90,99
 #define BN_MOM_D 0.1
@@ -89,6 +93,7 @@ struct explainn_ctx {
     int dsp_stride, dsp_count;   // partial slots per unit / how many of them the last conv_bwd wrote
     float* dlogits;       // [maxB][T]         (train_step only)
     float* dlT;           // [T][Bs]   d loss / d logits, task-major (head GEMMs, T > HEAD_GEMM_MIN_T)
+    float* gWp;           // [HEAD_GW_CHUNKS][T][U+1]  batch-chunk partials of the combiner-weight gradient
     double* lossp;        // [64]      per-block partial sums of the loss
     int staged_B;         // batch size of the codes explainn_stage_codes() staged, 0 = none
     // eval-mode tables (filter tables, BatchNorm1/2 folds, FC1 fragments) held in the scratch are

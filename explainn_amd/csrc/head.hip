@@ -14,7 +14,7 @@
 // element (k, row) at ptr[k*ld + row] (coalesced across the 32 rows of a tile).
 // ---------------------------------------------------------------------------------------------
 typedef float f32x16h __attribute__((ext_vector_type(16)));
-enum { EPI_PLAIN = 0, EPI_BIAS = 1, EPI_GW = 2 };
+enum { EPI_PLAIN = 0, EPI_BIAS = 1, EPI_GW = 2 };   // EPI_GW: gridDim.y batch chunks, partial tiles to D[chunk][M][N]
 
 template <bool A_KC, bool B_KC, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm32_kernel(const float* __restrict__ A, int lda,
@@ -31,8 +31,11 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(const float* __restrict_
     // EPI_GW: column N-1 is a virtual all-ones row of B (it yields the bias gradient)
     const bool ones_col = EPI == EPI_GW && j == N - 1;
     const int jc = min(j, (EPI == EPI_GW ? N - 2 : N - 1));
-    const int Kq = (K + 3) >> 2;                       // this wave's quarter [kq0, kq1)
-    const int kq0 = min(wave * Kq, K), kq1 = min(kq0 + Kq, K);
+    // (EPI_GW: this workgroup's chunk [kb0, kb1) of K; otherwise all of K)
+    const int Kc = ((K + (int)gridDim.y - 1) / (int)gridDim.y + 7) & ~7;
+    const int kb0 = min((int)blockIdx.y * Kc, K), kb1 = min(kb0 + Kc, K);
+    const int Kq = (kb1 - kb0 + 3) >> 2;               // this wave's quarter [kq0, kq1)
+    const int kq0 = min(kb0 + wave * Kq, kb1), kq1 = min(kq0 + Kq, kb1);
     const int Kh = (kq1 - kq0 + 1) >> 1;               // this half-wave's run [k0, kend)
     const int k0 = kq0 + kk * Kh, kend = min(k0 + Kh, kq1);
     const float* ap = A_KC ? A + (size_t)ic * lda : A + ic;
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(const float* __restrict_
             if (row >= M) continue;
             float v = ((acc[g] + part[0][g][lane]) + part[1][g][lane]) + part[2][g][lane];
             if (EPI == EPI_BIAS) v += bias[j];
-            if (EPI == EPI_GW && j == N - 1) extra[row] = v;
+            if (EPI == EPI_GW) D[((size_t)blockIdx.y * M + row) * N + j] = v;     // (bias column included)
             else D[(size_t)row * ldd + j] = v;
         }
     }
@@ -431,7 +434,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
     const float* __restrict__ g3, const float* __restrict__ o, const float* __restrict__ zhat,
     const float* __restrict__ sig3, float* __restrict__ dz, float* __restrict__ gWf,
     float* __restrict__ gbf, float* __restrict__ gg3, float* __restrict__ gb3,
-    float* __restrict__ gc2, int U, int T, int Bs, int B) {
+    float* __restrict__ gc2, int U, int T, int Bs, int B, const float* __restrict__ gWp = nullptr,
+    int gwch = 0) {
     __shared__ double red[4];
     __shared__ double red3[12];
     const int u = blockIdx.x, tid = threadIdx.x;
@@ -534,6 +538,25 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
         }
         return;
     }
+    if (GEMMED && gWp) {
+        // the combiner-weight gradient of this unit (and, in unit 0's block, the bias gradient): the
+        // GEMM's batch-chunk partials summed in chunk order, eight loads in flight
+        for (int e = tid; e < (u == 0 ? 2 * T : T); e += 256) {
+            const int t = e < T ? e : e - T, col = e < T ? u : U;
+            float sacc = 0.f;
+            for (int c0 = 0; c0 < gwch; c0 += 8) {
+                float pv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    pv[i] = gWp[((size_t)min(c0 + i, gwch - 1) * T + t) * (U + 1) + col];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) KEEP(pv[i]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sacc += (c0 + i < gwch) ? pv[i] : 0.f;
+            }
+            if (e < T) gWf[(size_t)t * U + u] = sacc; else gbf[t] = sacc;
+        }
+    }
     for (int t = 0; t < (GEMMED ? 0 : T); ++t) {
         double a = 0;
         for (int b = tid; b < B; b += 256)
@@ -575,15 +598,16 @@ int launch_head_bwd(explainn_ctx* c, const explainn_params* p, const explainn_gr
                            (float*)nullptr);
         LAUNCH_CHECK();
         // d Wf[t][u] = sum_b dl[b][t] o[u][b], and d bf[t] as the virtual all-ones unit U
+        const int gwch = head_gw_chunks(B);
         hipLaunchKernelGGL((gemm32_kernel<true, true, EPI_GW>),
-                           dim3(((T + 31) / 32) * ((U + 1 + 31) / 32)), dim3(256), 0, s, c->dlT, c->Bs,
-                           c->o, c->Bs, g->final_w, U, T, U + 1, B, (const float*)nullptr,
-                           g->final_b);
+                           dim3(((T + 31) / 32) * ((U + 1 + 31) / 32), gwch), dim3(256), 0, s, c->dlT, c->Bs,
+                           c->o, c->Bs, c->gWp, U + 1, T, U + 1, B, (const float*)nullptr,
+                           (float*)nullptr);
         LAUNCH_CHECK();
         hipLaunchKernelGGL((head_bwd_kernel<false, true>), dim3(U), dim3(256), 0, s, dlogits,
                            (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr,
                            p->final_w, p->bn3_w, c->o, c->zhat, c->sig3, c->dz, g->final_w,
-                           g->final_b, g->bn3_w, g->bn3_b, g->fc2_b, U, T, c->Bs, B);
+                           g->final_b, g->bn3_w, g->bn3_b, g->fc2_b, U, T, c->Bs, B, c->gWp, gwch);
         LAUNCH_CHECK();
         return EXPLAINN_OK;
     }
