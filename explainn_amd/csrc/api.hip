@@ -85,7 +85,7 @@ void carve(explainn_ctx* c, Carver& cv) {
     cv.take(&c->flags, 64);
     cv.take(&c->dlT, (int64_t)c->T * Bs);
     cv.take(&c->gWp, c->T > HEAD_GEMM_MIN_T ? (int64_t)head_gw_chunks(c->maxB) * c->T * (c->U + 1) : 0);
-    cv.take(&c->lossp, 64);
+    cv.take(&c->lossp, 256);
     cv.take(&c->site_cnt, U4 * Bs);
     cv.take(&c->site_off, U4 * Bs);
     cv.off = (cv.off + 255) & ~int64_t(255);
@@ -463,7 +463,7 @@ int train_step_front(explainn_ctx* c, const float* x, const float* targets, int 
         // few tasks: the loss gradient is recomputed inside the head backward (one launch less)
         STAGE(ST_HEAD_BWD, launch_head_bwd_fused_loss(c, p, g, loss_kind, logits, targets, loss_out, B, s));
     } else {
-        STAGE(ST_LOSS, explainn_loss_grad(c, loss_kind, logits, targets, B, loss_out, c->dlogits, stream));
+        STAGE(ST_LOSS, launch_loss_deferred(c, loss_kind, logits, targets, B, loss_out, c->dlogits, s));
         STAGE(ST_HEAD_BWD, launch_head_bwd(c, p, g, c->dlogits, B, s));
     }
     return backward_fc(c, B, p, g, nullptr, s);

@@ -93,6 +93,7 @@ struct explainn_ctx {
     int dsp_stride, dsp_count;   // partial slots per unit / how many of them the last conv_bwd wrote
     float* dlogits;       // [maxB][T]         (train_step only)
     float* dlT;           // [T][Bs]   d loss / d logits, task-major (head GEMMs, T > HEAD_GEMM_MIN_T)
+    int loss_blocks, loss_n; float* loss_out;   // a deferred loss value (launch_loss_deferred -> launch_head_bwd)
     float* gWp;           // [HEAD_GW_CHUNKS][T][U+1]  batch-chunk partials of the combiner-weight gradient
     double* lossp;        // [64]      per-block partial sums of the loss
     int staged_B;         // batch size of the codes explainn_stage_codes() staged, 0 = none
@@ -144,6 +145,8 @@ int launch_fc_fwd(explainn_ctx* c, const explainn_params* p, int B, bool train,
                   const uint8_t* keep_mask, float drop_p, uint64_t seed, hipStream_t s);
 int launch_head_fwd(explainn_ctx* c, const explainn_params* p, int B, bool train, float* logits,
                     float* outs, hipStream_t s);
+int launch_loss_deferred(explainn_ctx* c, int kind, const float* logits, const float* y, int B, float* loss,
+                         float* dlogits, hipStream_t s);
 int launch_loss(explainn_ctx* c, int kind, const float* logits, const float* y, int B,
                 float* loss, float* dlogits, hipStream_t s);
 int launch_head_bwd(explainn_ctx* c, const explainn_params* p, const explainn_grads* g,

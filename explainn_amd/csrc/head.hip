@@ -358,6 +358,10 @@ int launch_head_fwd(explainn_ctx* c, const explainn_params* p, int B, bool train
 // loss + dlogits; up to LOSS_BLOCKS blocks write one partial sum each, the last block to finish adds
 // them in index order -> deterministic whatever the arrival order
 constexpr int LOSS_BLOCKS = 64;
+// DEFER (the training step): the blocks leave their partial sums and the head backward that follows
+// adds them up -- the last-arriver finish below needs a device-scope fence in every block, and on
+// this multi-XCD part that write-back made a kernel with 200 K elements take 17 us.
+template <bool DEFER>
 __global__ __launch_bounds__(1024) void loss_kernel(const float* __restrict__ logits,
                                                     const float* __restrict__ y, int kind, int N,
                                                     float* __restrict__ loss,
@@ -369,23 +373,48 @@ __global__ __launch_bounds__(1024) void loss_kernel(const float* __restrict__ lo
     const int tid = threadIdx.x;
     const float invN = 1.0f / (float)N;
     double acc = 0;
-    for (int i = blockIdx.x * 1024 + tid; i < N; i += gridDim.x * 1024) {
-        const float x = logits[i], t = y[i];
-        float l, d;
-        if (kind == EXPLAINN_LOSS_BCE_WITH_LOGITS) {
-            l = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
-            d = (1.0f / (1.0f + expf(-x)) - t) * invN;
-        } else {
-            const float e = x - t;
-            l = e * e;
-            d = 2.0f * e * invN;
+    // four elements per thread per trip with their loads issued together (a block's eight trips of a
+    // run-time loop were eight memory round trips; the order of a thread's additions is unchanged)
+    const int stride = gridDim.x * 1024;
+    for (int i0 = blockIdx.x * 1024 + tid; i0 < N; i0 += 4 * stride) {
+        float xv[4], tv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ic = min(i0 + q * stride, N - 1);
+            xv[q] = logits[ic]; tv[q] = y[ic];
         }
-        acc += (double)l;
-        dlogits[i] = d;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { KEEP(xv[q]); KEEP(tv[q]); }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + q * stride;
+            if (i < N) {
+                const float x = xv[q], t = tv[q];
+                float l, d;
+                if (kind == EXPLAINN_LOSS_BCE_WITH_LOGITS) {
+                    l = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+                    d = (1.0f / (1.0f + expf(-x)) - t) * invN;
+                } else {
+                    const float e = x - t;
+                    l = e * e;
+                    d = 2.0f * e * invN;
+                }
+                acc += (double)l;
+                dlogits[i] = d;
+            }
+        }
     }
     acc = wave_sum_d(acc);
     if ((tid & 63) == 0) red[tid >> 6] = acc;
     __syncthreads();
+    if (DEFER) {
+        if (tid == 0) {
+            double s = 0;
+            for (int i = 0; i < 16; ++i) s += red[i];
+            partial[blockIdx.x] = s;
+        }
+        return;
+    }
     if (tid == 0) {
         double s = 0;
         for (int i = 0; i < 16; ++i) s += red[i];
@@ -407,9 +436,22 @@ int launch_loss(explainn_ctx* c, int kind, const float* logits, const float* y, 
                 float* dlogits, hipStream_t s) {
     const int N = B * c->T;
     const int blocks = min(LOSS_BLOCKS, (N + 8191) / 8192);
-    hipLaunchKernelGGL(loss_kernel, dim3(blocks), dim3(1024), 0, s, logits, y, kind, N, loss, dlogits,
+    hipLaunchKernelGGL(loss_kernel<false>, dim3(blocks), dim3(1024), 0, s, logits, y, kind, N, loss, dlogits,
                        c->lossp, c->flags + 1);
     LAUNCH_CHECK();
+    return EXPLAINN_OK;
+}
+
+// the training step's form: partial sums only; launch_head_bwd (which must follow) finishes the value
+int launch_loss_deferred(explainn_ctx* c, int kind, const float* logits, const float* y, int B, float* loss,
+                         float* dlogits, hipStream_t s) {
+    const int N = B * c->T;
+    // (no last-arriver finish here, so nothing limits the block count: one or two elements per thread)
+    const int blocks = min(256, (N + 1023) / 1024);
+    hipLaunchKernelGGL(loss_kernel<true>, dim3(blocks), dim3(1024), 0, s, logits, y, kind, N, loss, dlogits,
+                       c->lossp, c->flags + 1);
+    LAUNCH_CHECK();
+    c->loss_blocks = blocks; c->loss_out = loss; c->loss_n = N;
     return EXPLAINN_OK;
 }
 
@@ -435,7 +477,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
     const float* __restrict__ sig3, float* __restrict__ dz, float* __restrict__ gWf,
     float* __restrict__ gbf, float* __restrict__ gg3, float* __restrict__ gb3,
     float* __restrict__ gc2, int U, int T, int Bs, int B, const float* __restrict__ gWp = nullptr,
-    int gwch = 0) {
+    int gwch = 0, const double* __restrict__ lossp = nullptr, int lossb = 0, int lossn = 1) {
     __shared__ double red[4];
     __shared__ double red3[12];
     const int u = blockIdx.x, tid = threadIdx.x;
@@ -491,16 +533,39 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
             s2 = fma((double)d3r[i], live ? (double)zhr[i] : 0.0, s2);
         }
     } else {
+        if (GEMMED) {
+            // four sequences per thread per trip, their loads issued together (one sequence per trip of
+            // a run-time loop was one memory round trip each: sixteen in a row at batch 4096)
+            for (int b0 = tid; b0 < B; b0 += 4 * 256) {
+                float dv[4], ov[4], zv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int bc = min(b0 + 256 * i, B - 1);
+                    dv[i] = dzu[bc]; ov[i] = ou[bc]; zv[i] = zh[bc];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { KEEP(dv[i]); KEEP(ov[i]); KEEP(zv[i]); }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int b = b0 + 256 * i;
+                    if (b < B) {
+                        const float d3 = ov[i] > 0.f ? dv[i] : 0.f;
+                        dzu[b] = d3;
+                        s1 += (double)d3;
+                        s2 = fma((double)d3, (double)zv[i], s2);
+                    }
+                }
+            }
+        } else {
         for (int b = tid; b < B; b += 256) {
             float dob = 0.f;
-            if (GEMMED) dob = dzu[b];
-            else
-                for (int t = 0; t < T; ++t)
-                    dob = fmaf(dl_at<FUSED>(dl, logits, y, kind, invN, b * T + t), Wf[(size_t)t * U + u], dob);
+            for (int t = 0; t < T; ++t)
+                dob = fmaf(dl_at<FUSED>(dl, logits, y, kind, invN, b * T + t), Wf[(size_t)t * U + u], dob);
             const float d3 = ou[b] > 0.f ? dob : 0.f;
             dzu[b] = d3;
             s1 += (double)d3;
             s2 = fma((double)d3, (double)zh[b], s2);
+        }
         }
     }
     double S1 = s1, S2 = s2, G0 = gw[0];
@@ -517,7 +582,19 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
         for (int i = 0; i < RB; ++i)
             if (tid + 256 * i < B) dzu[tid + 256 * i] = sc * (d3r[i] - m1 - zhr[i] * m2);
     } else {
-        for (int b = tid; b < B; b += 256) dzu[b] = sc * (dzu[b] - m1 - zh[b] * m2);
+        for (int b0 = tid; b0 < B; b0 += 4 * 256) {
+            float dv[4], zv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int bc = min(b0 + 256 * i, B - 1);
+                dv[i] = dzu[bc]; zv[i] = zh[bc];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { KEEP(dv[i]); KEEP(zv[i]); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (b0 + 256 * i < B) dzu[b0 + 256 * i] = sc * (dv[i] - m1 - zv[i] * m2);
+        }
     }
     if (tid == 0) { gg3[u] = (float)S2; gb3[u] = (float)S1; gc2[u] = 0.f; }
     if (inreg) {
@@ -537,6 +614,12 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
             if (tid == 0) *loss_out = (float)(tot / (double)(B * T));
         }
         return;
+    }
+    if (lossb > 0 && u == 0) {
+        // the loss value: launch_loss_deferred's block partials (at most 256), one per thread, summed
+        // in the block's fixed tree order (block-uniform branch: the barriers inside are safe)
+        const double sl = block_sum_256(tid < lossb ? lossp[tid] : 0.0, red);
+        if (tid == 0) *loss_out = (float)(sl / (double)lossn);
     }
     if (GEMMED && gWp) {
         // the combiner-weight gradient of this unit (and, in unit 0's block, the bias gradient): the
@@ -605,17 +688,22 @@ int launch_head_bwd(explainn_ctx* c, const explainn_params* p, const explainn_gr
                            (float*)nullptr);
         LAUNCH_CHECK();
         hipLaunchKernelGGL((head_bwd_kernel<false, true>), dim3(U), dim3(256), 0, s, dlogits,
-                           (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, 0,
+                           c->loss_blocks ? c->loss_out : (float*)nullptr,
                            p->final_w, p->bn3_w, c->o, c->zhat, c->sig3, c->dz, g->final_w,
-                           g->final_b, g->bn3_w, g->bn3_b, g->fc2_b, U, T, c->Bs, B, c->gWp, gwch);
+                           g->final_b, g->bn3_w, g->bn3_b, g->fc2_b, U, T, c->Bs, B, c->gWp, gwch,
+                           c->lossp, c->loss_blocks, c->loss_n);
         LAUNCH_CHECK();
+        c->loss_blocks = 0;
         return EXPLAINN_OK;
     }
     hipLaunchKernelGGL(head_bwd_kernel<false>, dim3(c->U), dim3(256), 0, s, dlogits,
-                       (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr, p->final_w,
-                       p->bn3_w, c->o, c->zhat, c->sig3, c->dz, g->final_w, g->final_b, g->bn3_w,
-                       g->bn3_b, g->fc2_b, c->U, c->T, c->Bs, B);
+                       (const float*)nullptr, (const float*)nullptr, 0, c->loss_blocks ? c->loss_out : (float*)nullptr,
+                       p->final_w, p->bn3_w, c->o, c->zhat, c->sig3, c->dz, g->final_w, g->final_b, g->bn3_w,
+                       g->bn3_b, g->fc2_b, c->U, c->T, c->Bs, B, (const float*)nullptr, 0, c->lossp,
+                       c->loss_blocks, c->loss_n);
     LAUNCH_CHECK();
+    c->loss_blocks = 0;
     return EXPLAINN_OK;
 }
 
