@@ -51,17 +51,33 @@ def predict(model, Xs, batch_size=100, apply_sigmoid=False):
     chunk = max(int(batch_size), _CHUNK)
     out = np.empty((len(data), model._options["n_features"], 4))
     # the folded eval tables are built once for the whole loop (nothing writes parameters here);
-    # input validation is settled by ONE read of the sticky device flag after the last pass
-    with torch.no_grad(), model.eval_cache():
+    # input validation is settled by ONE read of the sticky device flag after the last pass.
+    # The two strands of a chunk are independent batches: the reverse strand runs on a replica of the
+    # model (same tensors, own device context: ExplaiNN.eval_replica) on a second stream, so that the
+    # launches of one strand fill the gaps between the dependent launches of the other.
+    rep = model.eval_replica()
+    cur = torch.cuda.current_stream(device)
+    if model._rt.side_stream is None:
+        model._rt.side_stream = torch.cuda.Stream(device)
+    side = model._rt.side_stream
+    with torch.no_grad(), model.eval_cache(), rep.eval_cache():
         for i in range(0, len(data), chunk):
             xb = data[i:i + chunk].to(device)
             if as_codes:
-                fwd, rev = model(BaseCodes(xb)), model(BaseCodes(xb, reverse_complement=True))
+                xf, xr = BaseCodes(xb), BaseCodes(xb, reverse_complement=True)
             else:
-                fwd, rev = model(xb), model(torch.flip(xb, dims=(1, 2)))   # rc_one_hot_encoding: both axes
+                xf, xr = xb, torch.flip(xb, dims=(1, 2))       # rc_one_hot_encoding: both axes
+            side.wait_stream(cur)                               # the chunk is on the device
+            with torch.cuda.stream(side):
+                rev = rep(xr)
+            fwd = model(xf)
+            cur.wait_stream(side)
+            rev.record_stream(cur)
             # numpy's float32 mean of two values is (a + b) / 2 in float32, as here
             both = torch.stack((fwd, rev, (fwd + rev) / 2, torch.maximum(fwd, rev)), dim=2)
             out[i:i + both.shape[0]] = both.cpu().numpy()
+    if model.validate_input:
+        rep.check_input()
     if model.validate_input:
         model.check_input()
     if apply_sigmoid:

@@ -903,3 +903,35 @@ def test_fc_bf16_piece_products_are_fp32_accurate():
     e_bf = np.abs(bf - ref).max() / scale
     record_margin("abs unit outputs vs fp64 (bf16 nine-piece fc_fwd)", e_bf, 3e-6)
     assert e_bf <= 3e-6, e_bf
+
+
+def test_eval_replica_shares_tensors_and_overlaps_on_a_second_stream():
+    """ExplaiNN.eval_replica(): a second handle on the same parameter tensors with its own device
+    context.  Two batches in flight on two streams give the numbers of two forwards in a row, bit for
+    bit; a parameter change through the model is seen by the replica."""
+    from explainn_amd.architectures import BaseCodes
+    U, k, L, T = 9, 19, 200, 3
+    sd = orc.random_state_dict(U, k, L, T, seed=5)
+    m = _model(sd, U, k, L, T).eval()
+    rep = m.eval_replica()
+    assert rep is m.eval_replica() and rep is not m
+    assert all(a is b for a, b in zip(m.parameters(), rep.parameters()))
+    rng = np.random.default_rng(1)
+    c1 = torch.from_numpy(rng.integers(0, 4, size=(300, L)).astype(np.uint8)).cuda()
+    c2 = torch.from_numpy(rng.integers(0, 4, size=(300, L)).astype(np.uint8)).cuda()
+    with torch.no_grad():
+        want1, want2 = m(c1).clone(), m(BaseCodes(c2, reverse_complement=True)).clone()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.no_grad(), m.eval_cache(), rep.eval_cache():
+        for _ in range(20):
+            with torch.cuda.stream(s1):
+                got1 = m(c1)
+            with torch.cuda.stream(s2):
+                got2 = rep(BaseCodes(c2, reverse_complement=True))
+    torch.cuda.synchronize()
+    assert torch.equal(got1, want1) and torch.equal(got2, want2)
+    with torch.no_grad():
+        m.final.bias.add_(1.0)
+        assert torch.allclose(rep(c1), want1 + 1.0, atol=1e-6)
+

@@ -21,6 +21,23 @@ for B in (100, 1024, 4096):
             torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
         print("eval B=%-5d %-9s %.3f ms/batch  %.2f M seq/s" % (B, name, dt * 1e3, B / dt / 1e6), flush=True)
 
+# two independent batches in flight: the model and its eval_replica() (same tensors, own context)
+# on two streams -- what predict() does with the two strands of a chunk
+rep = m.eval_replica()
+s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+for B in (1024, 4096):
+    codes = torch.randint(0, 4, (B, L)).to(torch.uint8).to(dev)
+    with torch.no_grad(), m.eval_cache(), rep.eval_cache():
+        for _ in range(50):
+            with torch.cuda.stream(s1): m(codes)
+            with torch.cuda.stream(s2): rep(codes)
+        torch.cuda.synchronize(); t0 = time.perf_counter(); K = 1000
+        for _ in range(K // 2):
+            with torch.cuda.stream(s1): m(codes)
+            with torch.cuda.stream(s2): rep(codes)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
+    print("eval B=%-5d codes, two contexts on two streams  %.3f ms/batch  %.2f M seq/s" % (B, dt * 1e3, B / dt / 1e6), flush=True)
+
 # the predict entry point on host data (N = 20000), reference default batch size
 import numpy as np
 from explainn_amd.predict import predict
