@@ -117,6 +117,41 @@ __device__ __forceinline__ void block_sum3_256(double& a, double& b, double& c, 
     c = (red12[8] + red12[9]) + (red12[10] + red12[11]);
 }
 
+// The register path of head_fwd_train: this thread's RBX z values stay in registers through the three
+// passes (mean, variance, normalise) -- one batch of loads instead of three passes of dependent round
+// trips over the same row.  RBX = 4 (batch <= 1024) or 16 (batch <= 4096: configuration C3).
+template <int RBX>
+__device__ __forceinline__ void head_fwd_train_regs(const float* __restrict__ zu, float* __restrict__ zhu,
+                                                    float* __restrict__ ou, float gam, float bet, int B,
+                                                    int tid, double* red, double& mean, double& var,
+                                                    double& sg) {
+    float zr[RBX];
+#pragma unroll
+    for (int i = 0; i < RBX; ++i) zr[i] = zu[min(tid + 256 * i, B - 1)];
+#pragma unroll
+    for (int i = 0; i < RBX; ++i) KEEP(zr[i]);
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < RBX; ++i) s += (tid + 256 * i < B) ? (double)zr[i] : 0.0;
+    mean = block_sum_256(s, red) / (double)B;
+    double v = 0;
+#pragma unroll
+    for (int i = 0; i < RBX; ++i)
+        if (tid + 256 * i < B) { const double d = (double)zr[i] - mean; v = fma(d, d, v); }
+    var = block_sum_256(v, red) / (double)B;
+    sg = sqrt(var + BN_EPS_D);
+    const float meanf = (float)mean, isg = (float)(1.0 / sg);
+#pragma unroll
+    for (int i = 0; i < RBX; ++i) {
+        const int b = tid + 256 * i;
+        if (b < B) {
+            const float zh = (zr[i] - meanf) * isg;
+            zhu[b] = zh;
+            ou[b] = fmaxf(fmaf(gam, zh, bet), 0.f);
+        }
+    }
+}
+
 // one block per unit: batch statistics of z, then zhat / o
 __global__ __launch_bounds__(256) void head_fwd_train_kernel(
     const float* __restrict__ z, const float* __restrict__ c2, const float* __restrict__ g3,
@@ -125,47 +160,21 @@ __global__ __launch_bounds__(256) void head_fwd_train_kernel(
     __shared__ double red[4];
     const int u = blockIdx.x, tid = threadIdx.x;
     const float* zu = z + (size_t)u * Bs;
-    // Batches up to HEAD_RB*256 sequences keep this thread's z values in registers: one batch of loads
-    // instead of three passes of dependent round trips over the same row.
-    constexpr int RB = HEAD_RB;
-    const bool inreg = B <= RB * 256;
-    float zr[RB];
-    if (inreg) {
-#pragma unroll
-        for (int i = 0; i < RB; ++i) zr[i] = zu[min(tid + 256 * i, B - 1)];
-#pragma unroll
-        for (int i = 0; i < RB; ++i) KEEP(zr[i]);
-    }
-    double s = 0;
-    if (inreg) {
-#pragma unroll
-        for (int i = 0; i < RB; ++i) s += (tid + 256 * i < B) ? (double)zr[i] : 0.0;
+    const float gam = g3[u], bet = b3[u];
+    double mean, var, sg;
+    if (B <= HEAD_RB * 256) {
+        head_fwd_train_regs<HEAD_RB>(zu, zhat + (size_t)u * Bs, o + (size_t)u * Bs, gam, bet, B, tid, red, mean, var, sg);
+    } else if (B <= 16 * 256) {
+        head_fwd_train_regs<16>(zu, zhat + (size_t)u * Bs, o + (size_t)u * Bs, gam, bet, B, tid, red, mean, var, sg);
     } else {
+        double s = 0;
         for (int b = tid; b < B; b += 256) s += (double)zu[b];
-    }
-    const double mean = block_sum_256(s, red) / (double)B;
-    double v = 0;
-    if (inreg) {
-#pragma unroll
-        for (int i = 0; i < RB; ++i)
-            if (tid + 256 * i < B) { const double d = (double)zr[i] - mean; v = fma(d, d, v); }
-    } else {
+        mean = block_sum_256(s, red) / (double)B;
+        double v = 0;
         for (int b = tid; b < B; b += 256) { const double d = (double)zu[b] - mean; v = fma(d, d, v); }
-    }
-    double var = block_sum_256(v, red) / (double)B;
-    const double sg = sqrt(var + BN_EPS_D);
-    const float meanf = (float)mean, isg = (float)(1.0 / sg), gam = g3[u], bet = b3[u];
-    if (inreg) {
-#pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            const int b = tid + 256 * i;
-            if (b < B) {
-                const float zh = (zr[i] - meanf) * isg;
-                zhat[(size_t)u * Bs + b] = zh;
-                o[(size_t)u * Bs + b] = fmaxf(fmaf(gam, zh, bet), 0.f);
-            }
-        }
-    } else {
+        var = block_sum_256(v, red) / (double)B;
+        sg = sqrt(var + BN_EPS_D);
+        const float meanf = (float)mean, isg = (float)(1.0 / sg);
         for (int b = tid; b < B; b += 256) {
             const float zh = (zu[b] - meanf) * isg;
             zhat[(size_t)u * Bs + b] = zh;
