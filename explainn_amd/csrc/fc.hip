@@ -653,6 +653,25 @@ __host__ __device__ constexpr int pa_ng(int NQ) { return (pa_nw16(NQ) + pa_wgt(N
 // The plain one -- what the headline shape launches -- does not hold pa_head_args' 18 pointers in
 // SGPRs across the main loop: with them passA<26> spilled 88 SGPRs and 12 VGPRs (20 B of scratch per
 // lane, tools/check_resources.py now fails the build on that).
+// passA's rows w = ROWS G + i turned into X[b][w] = dz q (w < n), dz (w == n: the Se column), 0 beyond.
+// n lies in (NQLO, NQ], the bucket the kernel is instantiated for, and G is a template argument, so
+// every row is classed at compile time: always there (w <= NQLO), never (w > NQ), or one of the few
+// in between that need a run-time test.  As nested selects on a run-time row index this was two
+// scalar branches per row (61 per 64 sequences at n = 26; with several row groups 226 branches and
+// their conditions spilled to lanes).
+template <int NQ, int G, int ROWS>
+__device__ __forceinline__ void pa_transform(float (&rq)[ROWS], float dzv, float a1, float sh1, int n) {
+    static_assert(pa_ng(NQ) <= 4, "passA dispatches at most four row groups");
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+        constexpr int W0 = G * ROWS;
+        const int w = W0 + i;
+        if (w <= nq_lower(NQ)) rq[i] = dzv * qval(a1, rq[i], sh1);
+        else if (w > NQ) rq[i] = 0.f;
+        else rq[i] = w < n ? dzv * qval(a1, rq[i], sh1) : (w == n ? dzv : 0.f);
+    }
+}
+
 template <int NQ, bool HEAD>
 __global__ __launch_bounds__(64 * PA_WAVES, pa_wgt(NQ) <= 2 ? 3 : 2) void passA_kernel(const float* __restrict__ ext,
                                                    const float* __restrict__ alpha,
@@ -730,17 +749,13 @@ __global__ __launch_bounds__(64 * PA_WAVES, pa_wgt(NQ) <= 2 ? 3 : 2) void passA_
         {
             // X[b][w] = dz q (w < n), dz (w == n: the Se column), 0 beyond; dead lanes carry zeros
             const float dzv = (b0 + lane < bend) ? rdz : 0.f;
-#pragma unroll
-            for (int i = 0; i < ROWS; ++i) {
-                // (n lies in (NQLO, NQ], the bucket this kernel is instantiated for: with one group
-                // of rows only the rows of that interval -- and row NQLO + 1 = a possible n -- need a
-                // run-time choice; as nested selects on every row this was two scalar branches per
-                // row, 61 per 64 sequences)
-                const int w = w0 + i;
-                if (pa_ng(NQ) == 1 && i <= nq_lower(NQ)) rq[i] = dzv * qval(a1, rq[i], sh1);
-                else if (pa_ng(NQ) == 1 && i > NQ) rq[i] = 0.f;
-                else rq[i] = w < n ? dzv * qval(a1, rq[i], sh1) : (w == n ? dzv : 0.f);
-            }
+            // one copy of the row loop per row group, chosen by ONE branch: inside a copy the row
+            // index is a compile-time constant (see pa_transform)
+            if constexpr (pa_ng(NQ) == 1) pa_transform<NQ, 0, ROWS>(rq, dzv, a1, sh1, n);
+            else if (grp == 0) pa_transform<NQ, 0, ROWS>(rq, dzv, a1, sh1, n);
+            else if (grp == 1) pa_transform<NQ, (pa_ng(NQ) > 1 ? 1 : 0), ROWS>(rq, dzv, a1, sh1, n);
+            else if (grp == 2) pa_transform<NQ, (pa_ng(NQ) > 2 ? 2 : 0), ROWS>(rq, dzv, a1, sh1, n);
+            else pa_transform<NQ, (pa_ng(NQ) > 3 ? 3 : 0), ROWS>(rq, dzv, a1, sh1, n);
         }
         // three bf16 pieces of every X value into the LDS image (the store takes the upper half of
         // the register)
